@@ -1,0 +1,535 @@
+/*
+ * oracle.c -- CPU restatement (plain C11, float64) of the reference hot path.
+ * TEST INFRASTRUCTURE ONLY -- see oracle.h.  Build: `make -C oracle` (gcc -O2 -ffp-contract=off).
+ * Reference paths are relative to /root/reference/main.
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NX 4
+#define NU 2
+
+/* ------------------------------------------------------------------ lib/mpc.py:58-79 */
+void orc_linear_model(double v, double phi, double delta, double dt, double L,
+                      double *A, double *B, double *C) {
+    memset(A, 0, 16 * sizeof(double));
+    memset(B, 0, 8 * sizeof(double));
+    memset(C, 0, 4 * sizeof(double));
+    A[0] = A[5] = A[10] = A[15] = 1.0;
+    A[0 * 4 + 2] = dt * cos(phi);
+    A[0 * 4 + 3] = -dt * v * sin(phi);
+    A[1 * 4 + 2] = dt * sin(phi);
+    A[1 * 4 + 3] = dt * v * cos(phi);
+    A[3 * 4 + 2] = dt * tan(delta) / L;
+    B[2 * 2 + 0] = dt;
+    double cd = cos(delta);
+    B[3 * 2 + 1] = dt * v / (L * (cd * cd));
+    C[0] = dt * v * sin(phi) * phi;
+    C[1] = -dt * v * cos(phi) * phi;
+    C[3] = -dt * v * delta / (L * (cd * cd));
+}
+
+/* ------------------------------------------------------------------ lib/mpc.py:129-135 */
+void orc_xy_cost_mtx(double angle, double *M) {
+    double c = cos(angle), s = sin(angle);
+    M[0] = c * c; M[1] = c * s; M[2] = c * s; M[3] = s * s;
+}
+
+/* ------------------------------------------------------------------ lib/mpc.py:43-55 */
+void orc_smooth_yaw(double *yaw, int32_t n) {
+    for (int32_t i = 0; i + 1 < n; i++) {
+        double d = yaw[i + 1] - yaw[i];
+        while (d >= M_PI / 2.0) { yaw[i + 1] -= M_PI * 2.0; d = yaw[i + 1] - yaw[i]; }
+        while (d <= -M_PI / 2.0) { yaw[i + 1] += M_PI * 2.0; d = yaw[i + 1] - yaw[i]; }
+    }
+}
+
+/* ------------------------------------------------------------------ lib/trajectories.py:100-126
+ * The three smallest distances in ascending order (numpy argpartition+argsort; ties, which numpy leaves
+ * unspecified, are broken here by lower index). */
+int32_t orc_nearest_index_in_direction(double x, double y, const double *cx, const double *cy, int32_t n,
+                                       int32_t start, int32_t forward) {
+    int32_t len = n - start;
+    if (len <= 1) return start;
+    if (len == 2) return forward ? 1 + start : start;
+    double bd[3] = {INFINITY, INFINITY, INFINITY};
+    int32_t bi[3] = {-1, -1, -1};
+    for (int32_t i = 0; i < len; i++) {
+        double dx = cx[start + i] - x, dy = cy[start + i] - y;
+        double d = sqrt(dx * dx + dy * dy);
+        if (d < bd[2]) {
+            int k = 2;
+            while (k > 0 && d < bd[k - 1]) { bd[k] = bd[k - 1]; bi[k] = bi[k - 1]; k--; }
+            bd[k] = d; bi[k] = i;
+        }
+    }
+    if (abs(bi[1] - bi[2]) == 2) return bi[0] + start;
+    if (abs(bi[0] - bi[1]) == 1) {
+        int32_t a = bi[0] > bi[1] ? bi[0] : bi[1], b = bi[0] < bi[1] ? bi[0] : bi[1];
+        return (forward ? a : b) + start;
+    }
+    return -1; /* reference raises Exception("something wrong") */
+}
+
+/* ------------------------------------------------------------------ lib/mpc.py:86-109 */
+int32_t orc_calc_ref_trajectory(const orc_mpc_params *p, const double *st, const double *cx, const double *cy,
+                                const double *cyaw, int32_t n, double dl, int32_t start_idx,
+                                double *xref, uint8_t *reaches_end) {
+    int32_t T = p->T, W = T + 1;
+    int32_t s = orc_nearest_index_in_direction(st[0], st[1], cx, cy, n, start_idx, 1);
+    if (s < 0) return -1;
+    double ov = st[2] > 10.0 / 3.6 ? st[2] : 10.0 / 3.6;   /* max(state.v, 10/3.6); ov is None with MAX_ITER=1 */
+    double step = fabs(ov) * p->dt, travel = 0.0;
+    for (int32_t k = 0; k < W; k++) {
+        travel = (k == 0) ? step : travel + step;          /* np.cumsum: sequential adds */
+        long idx = (long)nearbyint(travel / dl);           /* np.rint: half-to-even under the default rounding mode */
+        idx += s;
+        if (idx > n - 1) idx = n - 1;
+        xref[0 * W + k] = cx[idx];
+        xref[1 * W + k] = cy[idx];
+        xref[2 * W + k] = 0.0;
+        xref[3 * W + k] = cyaw[idx];
+        reaches_end[k] = (idx == n - 1);
+    }
+    return s;
+}
+
+/* ------------------------------------------------------------------ lib/simulation.py:35-47 + bicycle/main.py:28-41 */
+void orc_plant_step(const orc_mpc_params *p, double *s, double a, double delta) {
+    if (delta > p->max_steer) delta = p->max_steer;
+    if (delta < -p->max_steer) delta = -p->max_steer;
+    double v = s[2], th = s[3];
+    double xd = v * cos(th), yd = v * sin(th), td = (v / p->L) * tan(delta);
+    s[0] += xd * p->dt;
+    s[1] += yd * p->dt;
+    s[3] += td * p->dt;
+    v += a * p->dt;
+    if (v > p->max_speed) v = p->max_speed;
+    if (v < p->min_speed) v = p->min_speed;
+    s[2] = v;
+}
+
+/* ------------------------------------------------------------------ lib/mpc.py:112-126 */
+void orc_predict_motion(const orc_mpc_params *p, const double *x0, const double *oa, const double *od, double *xbar) {
+    int32_t T = p->T, W = T + 1;
+    double s[4] = {x0[0], x0[1], x0[2], x0[3]};
+    for (int i = 0; i < 4; i++) xbar[i * W] = x0[i];
+    for (int32_t t = 1; t <= T; t++) {
+        orc_plant_step(p, s, oa[t - 1], od[t - 1]);
+        for (int i = 0; i < 4; i++) xbar[i * W + t] = s[i];
+    }
+}
+
+/* ------------------------------------------------------------------ lib/mpc.py:138-208 : QP construction
+ * Generic dense condensing: x_t = S_t u + c_t with S_{t+1} = A_t S_t + B_t E_t, c_{t+1} = A_t c_t + C_t, c_0 = x0.
+ * u is interleaved [a_0, delta_0, a_1, delta_1, ...].  Objective exactly as cvxpy sums it (no 1/2 factors),
+ * expressed as 1/2 u'Hu + g'u (+const). Rows of G: per t (a<=, -a<=, d<=, -d<=), rate rows, speed rows t=1..T. */
+int32_t orc_qp_build(const orc_mpc_params *p, const double *x0, const double *xref, const double *xbar,
+                     const uint8_t *re, double *H, double *g, double *G, double *h, double *S, double *c) {
+    int32_t T = p->T, W = T + 1, n = 2 * T;
+    int32_t m = 4 * T + 2 * (T - 1) + 2 * T;
+    memset(H, 0, sizeof(double) * n * n);
+    memset(g, 0, sizeof(double) * n);
+    memset(G, 0, sizeof(double) * m * n);
+    memset(S, 0, sizeof(double) * W * 4 * n);
+    for (int i = 0; i < 4; i++) c[i] = x0[i];
+    for (int32_t t = 0; t < T; t++) {
+        double A[16], B[8], C[4];
+        orc_linear_model(xbar[2 * W + t], xbar[3 * W + t], 0.0 /* dref is zeroed, mpc.py:93 */, p->dt, p->L, A, B, C);
+        const double *St = S + (size_t)t * 4 * n;
+        double *Sn = S + (size_t)(t + 1) * 4 * n;
+        for (int i = 0; i < 4; i++) {
+            for (int k = 0; k < n; k++) {
+                double acc = 0.0;
+                for (int j = 0; j < 4; j++) acc += A[i * 4 + j] * St[j * n + k];
+                Sn[i * n + k] = acc;
+            }
+            Sn[i * n + 2 * t + 0] += B[i * 2 + 0];
+            Sn[i * n + 2 * t + 1] += B[i * 2 + 1];
+            double acc = C[i];
+            for (int j = 0; j < 4; j++) acc += A[i * 4 + j] * c[t * 4 + j];
+            c[(t + 1) * 4 + i] = acc;
+        }
+    }
+    /* state costs, t = 1..T (mpc.py:157-170) */
+    for (int32_t t = 1; t <= T; t++) {
+        double Wt[16];
+        memset(Wt, 0, sizeof Wt);
+        if (!re[t]) {
+            double Mp[4], Ma[4];
+            orc_xy_cost_mtx(xref[3 * W + t] + 0.5 * M_PI, Mp);
+            orc_xy_cost_mtx(xref[3 * W + t], Ma);
+            Wt[0] = Mp[0] * p->w_perp + Ma[0] * p->w_para;
+            Wt[1] = Mp[1] * p->w_perp + Ma[1] * p->w_para;
+            Wt[4] = Mp[2] * p->w_perp + Ma[2] * p->w_para;
+            Wt[5] = Mp[3] * p->w_perp + Ma[3] * p->w_para;
+            Wt[10] = p->Q_v_yaw[0];
+            Wt[15] = p->Q_v_yaw[1];
+        } else {
+            for (int i = 0; i < 4; i++) Wt[i * 4 + i] = p->Qf[i];
+        }
+        const double *St = S + (size_t)t * 4 * n;
+        double e[4], We[4];
+        for (int i = 0; i < 4; i++) e[i] = c[t * 4 + i] - xref[i * W + t];
+        for (int i = 0; i < 4; i++) { We[i] = 0; for (int j = 0; j < 4; j++) We[i] += Wt[i * 4 + j] * e[j]; }
+        for (int a = 0; a < n; a++) {
+            double WS[4];
+            for (int i = 0; i < 4; i++) { WS[i] = 0; for (int j = 0; j < 4; j++) WS[i] += Wt[i * 4 + j] * St[j * n + a]; }
+            for (int b = 0; b < n; b++) {
+                double acc = 0;
+                for (int i = 0; i < 4; i++) acc += St[i * n + b] * WS[i];
+                H[b * n + a] += 2.0 * acc;
+            }
+            double acc = 0;
+            for (int i = 0; i < 4; i++) acc += St[i * n + a] * We[i];
+            g[a] += 2.0 * acc;
+        }
+    }
+    /* input costs (mpc.py:177-180) and rate costs (mpc.py:182-183) */
+    for (int32_t t = 0; t < T; t++) {
+        const double *Rt = re[t] ? p->R_end : p->R;
+        H[(2 * t) * n + 2 * t] += 2.0 * Rt[0];
+        H[(2 * t + 1) * n + 2 * t + 1] += 2.0 * Rt[1];
+    }
+    for (int32_t t = 0; t + 1 < T; t++)
+        for (int j = 0; j < 2; j++) {
+            int a = 2 * t + j, b = 2 * (t + 1) + j;
+            H[a * n + a] += 2.0 * p->Rd[j];
+            H[b * n + b] += 2.0 * p->Rd[j];
+            H[a * n + b] -= 2.0 * p->Rd[j];
+            H[b * n + a] -= 2.0 * p->Rd[j];
+        }
+    /* constraints (mpc.py:184-191) */
+    int32_t r = 0;
+    for (int32_t t = 0; t < T; t++) {
+        G[r * n + 2 * t] = 1.0;      h[r++] = p->max_accel;
+        G[r * n + 2 * t] = -1.0;     h[r++] = -p->max_decel;
+        G[r * n + 2 * t + 1] = 1.0;  h[r++] = p->max_steer;
+        G[r * n + 2 * t + 1] = -1.0; h[r++] = p->max_steer;
+    }
+    for (int32_t t = 0; t + 1 < T; t++) {
+        G[r * n + 2 * t + 3] = 1.0;  G[r * n + 2 * t + 1] = -1.0; h[r++] = p->max_dsteer * p->dt;
+        G[r * n + 2 * t + 3] = -1.0; G[r * n + 2 * t + 1] = 1.0;  h[r++] = p->max_dsteer * p->dt;
+    }
+    for (int32_t t = 1; t <= T; t++) {
+        const double *St = S + (size_t)t * 4 * n;
+        for (int k = 0; k < n; k++) G[r * n + k] = St[2 * n + k];
+        h[r++] = p->max_speed - c[t * 4 + 2];
+        for (int k = 0; k < n; k++) G[r * n + k] = -St[2 * n + k];
+        h[r++] = c[t * 4 + 2] - p->min_speed;
+    }
+    return r;
+}
+
+/* dense Cholesky (lower), in place; returns 0 on success */
+static int chol(double *M, int n) {
+    for (int j = 0; j < n; j++) {
+        double d = M[j * n + j];
+        for (int k = 0; k < j; k++) d -= M[j * n + k] * M[j * n + k];
+        if (!(d > 0.0)) return 1;
+        d = sqrt(d);
+        M[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = M[i * n + j];
+            for (int k = 0; k < j; k++) s -= M[i * n + k] * M[j * n + k];
+            M[i * n + j] = s / d;
+        }
+    }
+    return 0;
+}
+static void chol_solve(const double *Lm, int n, double *b) {
+    for (int i = 0; i < n; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= Lm[i * n + k] * b[k];
+        b[i] = s / Lm[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < n; k++) s -= Lm[k * n + i] * b[k];
+        b[i] = s / Lm[i * n + i];
+    }
+}
+
+/* ------------------------------------------------------------------ lib/mpc.py:193-206 : the solve.
+ * The reference hands the problem to ECOS (an interior-point SOCP code).  The problem is a strictly convex QP
+ * (unique minimiser), restated here as a dense Mehrotra predictor-corrector primal-dual interior-point method
+ * on the condensed form.  Output: x (4,T+1), u (2,T) laid out as the reference's x.value / u.value. */
+int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xref, const double *xbar,
+                     const uint8_t *re, const double *u_warm, double *x_out, double *u_out, double *lam_out,
+                     int32_t *iters, double *kkt4) {
+    int32_t T = p->T, W = T + 1, n = 2 * T, mcap = 8 * T;
+    double *H = malloc(sizeof(double) * n * n), *g = malloc(sizeof(double) * n);
+    double *G = malloc(sizeof(double) * mcap * n), *h = malloc(sizeof(double) * mcap);
+    double *S = malloc(sizeof(double) * W * 4 * n), *c = malloc(sizeof(double) * W * 4);
+    double *M = malloc(sizeof(double) * n * n);
+    double *u = calloc(n, sizeof(double)), *du = malloc(sizeof(double) * n), *rd = malloc(sizeof(double) * n);
+    double *s = malloc(sizeof(double) * mcap), *lam = malloc(sizeof(double) * mcap), *rp = malloc(sizeof(double) * mcap);
+    double *ds = malloc(sizeof(double) * mcap), *dl = malloc(sizeof(double) * mcap), *rc = malloc(sizeof(double) * mcap);
+    double *dsa = malloc(sizeof(double) * mcap), *dla = malloc(sizeof(double) * mcap), *w = malloc(sizeof(double) * mcap);
+    int32_t m = orc_qp_build(p, x0, xref, xbar, re, H, g, G, h, S, c);
+    int32_t status = ORC_MAXITER, it = 0;
+    double res_d = 0, res_p = 0, mu = 0;
+
+    /* x[2,0] bounds are constant rows (mpc.py:187-188 include t=0) */
+    if (x0[2] > p->max_speed + 1e-9 || x0[2] < p->min_speed - 1e-9) { status = ORC_INFEASIBLE; goto done; }
+
+    if (u_warm) for (int t = 0; t < T; t++) { u[2 * t] = u_warm[t]; u[2 * t + 1] = u_warm[T + t]; }
+    for (int i = 0; i < m; i++) {
+        double gi = 0; for (int k = 0; k < n; k++) gi += G[i * n + k] * u[k];
+        double si = h[i] - gi;
+        s[i] = si > 0.5 ? si : 0.5;
+        lam[i] = 1.0;
+    }
+    double gnorm = 1.0, hnorm = 1.0;
+    for (int k = 0; k < n; k++) if (fabs(g[k]) > gnorm) gnorm = fabs(g[k]);
+    for (int i = 0; i < m; i++) if (fabs(h[i]) > hnorm) hnorm = fabs(h[i]);
+
+    for (it = 0; it <= p->max_iter; it++) {
+        res_d = 0; res_p = 0; mu = 0;
+        for (int k = 0; k < n; k++) {
+            double a = g[k];
+            for (int j = 0; j < n; j++) a += H[k * n + j] * u[j];
+            for (int i = 0; i < m; i++) a += G[i * n + k] * lam[i];
+            rd[k] = a; if (fabs(a) > res_d) res_d = fabs(a);
+        }
+        for (int i = 0; i < m; i++) {
+            double a = s[i] - h[i];
+            for (int k = 0; k < n; k++) a += G[i * n + k] * u[k];
+            rp[i] = a; if (fabs(a) > res_p) res_p = fabs(a);
+            mu += s[i] * lam[i];
+        }
+        mu /= m;
+        if (res_d <= p->tol * gnorm && res_p <= p->tol * hnorm && mu <= p->tol) { status = ORC_OK; break; }
+        if (it == p->max_iter) break;
+        /* M = H + G' D G */
+        memcpy(M, H, sizeof(double) * n * n);
+        for (int i = 0; i < m; i++) {
+            double d = lam[i] / s[i];
+            const double *Gi = G + (size_t)i * n;
+            for (int a = 0; a < n; a++) {
+                if (Gi[a] == 0.0) continue;
+                double da = d * Gi[a];
+                for (int b = 0; b <= a; b++) M[a * n + b] += da * Gi[b];
+            }
+        }
+        if (chol(M, n)) { status = ORC_NUMERIC; break; }
+        /* predictor */
+        for (int i = 0; i < m; i++) w[i] = -lam[i] + (lam[i] / s[i]) * rp[i];   /* (-rc + lam*rp)/s with rc = s*lam */
+        for (int k = 0; k < n; k++) { double a = -rd[k]; for (int i = 0; i < m; i++) a -= G[i * n + k] * w[i]; du[k] = a; }
+        chol_solve(M, n, du);
+        double alpha = 1.0;
+        for (int i = 0; i < m; i++) {
+            double gd = 0; for (int k = 0; k < n; k++) gd += G[i * n + k] * du[k];
+            dsa[i] = -rp[i] - gd;
+            dla[i] = -lam[i] - (lam[i] / s[i]) * dsa[i];
+            if (dsa[i] < 0 && -s[i] / dsa[i] < alpha) alpha = -s[i] / dsa[i];
+            if (dla[i] < 0 && -lam[i] / dla[i] < alpha) alpha = -lam[i] / dla[i];
+        }
+        double mu_aff = 0;
+        for (int i = 0; i < m; i++) mu_aff += (s[i] + alpha * dsa[i]) * (lam[i] + alpha * dla[i]);
+        mu_aff /= m;
+        double sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
+        /* corrector */
+        for (int i = 0; i < m; i++) {
+            rc[i] = s[i] * lam[i] + dsa[i] * dla[i] - sigma * mu;
+            w[i] = (-rc[i] + lam[i] * rp[i]) / s[i];
+        }
+        for (int k = 0; k < n; k++) { double a = -rd[k]; for (int i = 0; i < m; i++) a -= G[i * n + k] * w[i]; du[k] = a; }
+        chol_solve(M, n, du);
+        alpha = 1.0;
+        double amax = 1e300;
+        for (int i = 0; i < m; i++) {
+            double gd = 0; for (int k = 0; k < n; k++) gd += G[i * n + k] * du[k];
+            ds[i] = -rp[i] - gd;
+            dl[i] = -(rc[i] + lam[i] * ds[i]) / s[i];
+            if (ds[i] < 0 && -s[i] / ds[i] < amax) amax = -s[i] / ds[i];
+            if (dl[i] < 0 && -lam[i] / dl[i] < amax) amax = -lam[i] / dl[i];
+        }
+        alpha = 0.995 * amax; if (alpha > 1.0) alpha = 1.0;
+        for (int k = 0; k < n; k++) u[k] += alpha * du[k];
+        for (int i = 0; i < m; i++) { s[i] += alpha * ds[i]; lam[i] += alpha * dl[i]; }
+    }
+done:
+    *iters = it;
+    if (kkt4) {
+        /* certificate on the final iterate: stationarity, primal violation, complementarity, max(lam<0) */
+        double st = 0, pv = 0, cp = 0;
+        if (status != ORC_INFEASIBLE) {
+            for (int k = 0; k < n; k++) {
+                double a = g[k];
+                for (int j = 0; j < n; j++) a += H[k * n + j] * u[j];
+                for (int i = 0; i < m; i++) a += G[i * n + k] * lam[i];
+                if (fabs(a) > st) st = fabs(a);
+            }
+            for (int i = 0; i < m; i++) {
+                double a = -h[i];
+                for (int k = 0; k < n; k++) a += G[i * n + k] * u[k];
+                if (a > pv) pv = a;
+                if (fabs(a * lam[i]) > cp) cp = fabs(a * lam[i]);
+            }
+        }
+        kkt4[0] = st; kkt4[1] = pv; kkt4[2] = cp; kkt4[3] = mu;
+    }
+    for (int t = 0; t < T; t++) { u_out[t] = u[2 * t]; u_out[T + t] = u[2 * t + 1]; }
+    for (int t = 0; t <= T; t++)
+        for (int i = 0; i < 4; i++) {
+            double a = c[t * 4 + i];
+            for (int k = 0; k < n; k++) a += S[((size_t)t * 4 + i) * n + k] * u[k];
+            x_out[i * W + t] = a;
+        }
+    if (lam_out) for (int i = 0; i < m; i++) lam_out[i] = lam[i];
+    free(H); free(g); free(G); free(h); free(S); free(c); free(M); free(u); free(du); free(rd);
+    free(s); free(lam); free(rp); free(ds); free(dl); free(rc); free(dsa); free(dla); free(w);
+    return status;
+}
+
+/* ------------------------------------------------------------------ lib/maths.py:4-10 */
+static double normalize_angle(double th) {
+    const double tau = 2.0 * M_PI;
+    th = fmod(th, tau);
+    if (th < 0) th += tau;          /* python float % : result has the sign of the divisor */
+    if (th >= tau) th = 0.0;        /* python: (-1e-17) % tau == tau after rounding -> stays tau; handled below */
+    if (th >= M_PI) th -= tau;
+    return th;
+}
+
+/* ------------------------------------------------------------------ motion_primitive_search.py:87-121
+ * transform (linalg.py:4-54) + per-obstacle half-plane test (obstacles.py:157-176).  `collide[k]` is the
+ * reference's `collides` flag; `nbr` is filled for every primitive (callers ignore it where collide = 1).
+ * Products are kept un-fused in the two orders numpy/OpenBLAS was observed to use:
+ *   N>=2 points: (x*m0 + y*m1) + t with the first product rounded, second fused;  N==1: fma(x, m0, y*m1) + t. */
+void orc_expand(const orc_search_model *m, int32_t n_nodes, const double *nodes, const double *cs,
+                double *nbr, uint8_t *collide) {
+    int32_t P = m->n_prim;
+    for (int32_t q = 0; q < n_nodes; q++) {
+        double x = nodes[3 * q], y = nodes[3 * q + 1], th = nodes[3 * q + 2];
+        double c = cs ? cs[2 * q] : cos(th), s = cs ? cs[2 * q + 1] : sin(th);
+        int rot_only = (x == 0.0 && y == 0.0);   /* linalg.py:13-17: 2x2 matrix, no translation */
+        double tx = rot_only ? 0.0 : x, ty = rot_only ? 0.0 : y;
+        for (int32_t k = 0; k < P; k++) {
+            int hit = 0;
+            for (int32_t o = 0; o < m->n_obst && !hit; o++) {
+                for (int32_t i = m->tmpl_off[k]; i < m->tmpl_off[k + 1] && !hit; i++) {
+                    double px = m->tmpl_xy[2 * i], py = m->tmpl_xy[2 * i + 1];
+                    double wx = fma(py, -s, px * c) + tx;
+                    double wy = fma(py, c, px * s) + ty;
+                    int inside = 1;
+                    for (int32_t r = m->hp_off[o]; r < m->hp_off[o + 1]; r++) {
+                        const double *hp = m->hp + 3 * r;
+                        double v = hp[0] * wx + hp[1] * wy + hp[2];
+                        if (!(v <= 0.0)) { inside = 0; break; }
+                    }
+                    if (inside) hit = 1;
+                }
+            }
+            collide[q * P + k] = (uint8_t)hit;
+            const double *lp = m->last_pose + 3 * k;
+            double *o3 = nbr + ((size_t)q * P + k) * 3;
+            o3[0] = fma(lp[0], c, lp[1] * -s) + tx;
+            o3[1] = fma(lp[0], s, lp[1] * c) + ty;
+            o3[2] = normalize_angle(lp[2] + th);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ lib/trajectories.py:58-86 */
+int32_t orc_resample_curve(const double *pts, int32_t n, int32_t stride, const double *dl_vec, double dl,
+                           int32_t keep_last, int32_t *keep) {
+    int32_t cnt = 0;
+    double cum = 0.0;
+    long prev = 0;
+    for (int32_t i = 0; i < n; i++) {
+        if (i > 0) {
+            double dx = pts[i * stride] - pts[(i - 1) * stride], dy = pts[i * stride + 1] - pts[(i - 1) * stride + 1];
+            cum += sqrt(dx * dx + dy * dy);
+        }
+        long q = (long)floor(cum / (dl_vec ? dl_vec[i] : dl));
+        int k = (i == 0) || (q - prev >= 1) || (keep_last && i == n - 1);
+        prev = q;
+        if (k) keep[cnt++] = i;
+    }
+    return cnt;
+}
+
+/* ------------------------------------------------------------------ lib/moving_obstacles_prediction.py:21-47 */
+void orc_predict_obstacle(const double *six, double dt, double L, int32_t steps, double *out) {
+    double x = six[0], y = six[1], v = six[2], yaw = six[3], a = six[4], st = six[5];
+    for (int32_t k = 0; k < steps; k++) {
+        x += v * cos(yaw) * dt;
+        y += v * sin(yaw) * dt;
+        v += a * dt;
+        yaw += (v / L) * tan(st) * dt;     /* uses the UPDATED v (order differs from the plant) */
+        out[4 * k] = x; out[4 * k + 1] = y; out[4 * k + 2] = yaw; out[4 * k + 3] = k * dt;
+    }
+}
+
+/* disc centre of pose (x,y,th) : trajectories.py:11-37 */
+static void disc_xy(const double *pose, const double *cc, double *o) {
+    double c = cos(pose[2]), s = sin(pose[2]);
+    o[0] = (c * cc[0] - s * cc[1]) + pose[0];
+    o[1] = (s * cc[0] + c * cc[1]) + pose[1];
+}
+
+/* ------------------------------------------------------------------ lib/collision_avoidance.py:66-104
+ * Row order of the reference's flattened pair table (derived from _get_rowwise_diffs :32-46 and
+ * _offset_trajectories_by_frames :49-63): frame f (major), agent disc ca, obstacle o, offset index, obstacle disc co.
+ * Shifted obstacle pose at frame f, offset d: traj_o[clamp(f - d, 0, last)]; all trajectories are edge-padded
+ * to F = max(na, nsteps) frames. */
+int32_t orc_check_collision_moving_cars(const double *centers, int32_t nc, double radius,
+                                        const double *ta, int32_t na, const double *path, int32_t np_,
+                                        const double *tobs, int32_t nobs, int32_t nsteps, int32_t w, double *hit_xy) {
+    if (nobs == 0) return -1;
+    double md = 2.0 * radius;
+    int32_t F = na > nsteps ? na : nsteps;
+    for (int32_t f = 0; f < F; f++) {
+        const double *pa = ta + 3 * (f < na ? f : na - 1);
+        for (int32_t ca = 0; ca < nc; ca++) {
+            double a[2];
+            disc_xy(pa, centers + 2 * ca, a);
+            for (int32_t o = 0; o < nobs; o++)
+                for (int32_t d = -w; d <= w; d++) {
+                    int32_t ff = f < nsteps ? f : nsteps - 1;   /* padded obstacle frame */
+                    int32_t gidx;
+                    /* offset applied on the un-padded 'nsteps'-long trajectory, then padded to F */
+                    if (d < 0) { gidx = ff - d; if (gidx > nsteps - 1) gidx = nsteps - 1; }
+                    else if (d > 0) { gidx = ff - d; if (gidx < 0) gidx = 0; }
+                    else gidx = ff;
+                    const double *po = tobs + ((size_t)o * nsteps + gidx) * 4;
+                    double pose[3] = {po[0], po[1], po[2]};
+                    for (int32_t co = 0; co < nc; co++) {
+                        double b[2];
+                        disc_xy(pose, centers + 2 * co, b);
+                        double dx = a[0] - b[0], dy = a[1] - b[1];
+                        if (sqrt(dx * dx + dy * dy) <= md) {
+                            /* earliest pose of the detailed path whose disc (front block first) is within md */
+                            int32_t first = 0;
+                            for (int32_t cc = 0; cc < nc; cc++) {
+                                int found = 0;
+                                for (int32_t i = 0; i < np_; i++) {
+                                    double q[2];
+                                    disc_xy(path + 3 * i, centers + 2 * cc, q);
+                                    double ex = b[0] - q[0], ey = b[1] - q[1];
+                                    if (sqrt(ex * ex + ey * ey) <= md) { first = i; found = 1; break; }
+                                }
+                                if (found) break;
+                            }
+                            hit_xy[0] = path[3 * first]; hit_xy[1] = path[3 * first + 1];
+                            return first;
+                        }
+                    }
+                }
+        }
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------ lib/collision_avoidance.py:107-119 */
+int32_t orc_cutoff_idx(const double *pts, int32_t n, double x, double y, double radius) {
+    for (int32_t i = 0; i < n; i++) {
+        double dx = pts[3 * i] - x, dy = pts[3 * i + 1] - y;
+        if (sqrt(dx * dx + dy * dy) <= radius) return i;
+    }
+    return -1;
+}

@@ -1,0 +1,287 @@
+"""ctypes binding of oracle/liboracle.so plus the pure-Python parts of the oracle (A* queue, MPC step glue).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package never imports this module.
+"""
+import ctypes as C
+import heapq
+import math
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_bp = C.POINTER(C.c_uint8)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, 'liboracle.so')
+    src = [os.path.join(_HERE, f) for f in ('oracle.c', 'oracle.h')]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle.so'], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, 'liboracle.so')
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_nearest_index_in_direction.argtypes = [C.c_double, C.c_double, c_dp, c_dp, C.c_int32, C.c_int32, C.c_int32]
+        _LIB.orc_nearest_index_in_direction.restype = C.c_int32
+        _LIB.orc_calc_ref_trajectory.restype = C.c_int32
+        _LIB.orc_qp_build.restype = C.c_int32
+        _LIB.orc_qp_solve.restype = C.c_int32
+        _LIB.orc_resample_curve.restype = C.c_int32
+        _LIB.orc_check_collision_moving_cars.restype = C.c_int32
+        _LIB.orc_cutoff_idx.restype = C.c_int32
+        _LIB.orc_linear_model.argtypes = [C.c_double] * 5 + [c_dp] * 3
+        _LIB.orc_xy_cost_mtx.argtypes = [C.c_double, c_dp]
+    return _LIB
+
+
+def _d(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(c_ip)
+
+
+def _b(a):
+    return a.ctypes.data_as(c_bp)
+
+
+class _CParams(C.Structure):
+    _fields_ = [('T', C.c_int32), ('max_iter', C.c_int32), ('dt', C.c_double), ('L', C.c_double),
+                ('w_perp', C.c_double), ('w_para', C.c_double), ('R', C.c_double * 2), ('Rd', C.c_double * 2),
+                ('Q_v_yaw', C.c_double * 2), ('Qf', C.c_double * 4), ('R_end', C.c_double * 2),
+                ('max_speed', C.c_double), ('min_speed', C.c_double), ('max_accel', C.c_double),
+                ('max_decel', C.c_double), ('max_steer', C.c_double), ('max_dsteer', C.c_double), ('tol', C.c_double)]
+
+
+@dataclass
+class MpcParams:
+    """main/config/mpc_config.json + lib/mpc.py:17-36 + lib/simulation.py:23-25"""
+    T: int = 13
+    dt: float = 0.2
+    L: float = 2.86
+    w_perp: float = 20.0
+    w_para: float = 1.0
+    R: tuple = (0.01, 0.01)
+    Rd: tuple = (0.01, 1.0)
+    Q_v_yaw: tuple = (0.0, 0.5)
+    Qf_base: tuple = (1.0, 1.0, 0.0, 0.5)
+    R_end: tuple = (10.0, 10.0)
+    max_speed: float = 30.0 / 3.6
+    min_speed: float = -5.0
+    max_accel: float = 2.0
+    max_decel: float = -10.0
+    max_steer: float = float(np.deg2rad(45.0))
+    max_dsteer: float = float(np.deg2rad(30.0))
+    max_iter: int = 60
+    tol: float = 1e-10
+
+    def c(self):
+        p = _CParams()
+        p.T, p.max_iter, p.dt, p.L = self.T, self.max_iter, self.dt, self.L
+        p.w_perp, p.w_para = self.w_perp, self.w_para
+        p.R[:] = self.R; p.Rd[:] = self.Rd; p.Q_v_yaw[:] = self.Q_v_yaw
+        p.Qf[:] = [q * self.T for q in self.Qf_base]
+        p.R_end[:] = self.R_end
+        p.max_speed, p.min_speed, p.max_accel, p.max_decel = self.max_speed, self.min_speed, self.max_accel, self.max_decel
+        p.max_steer, p.max_dsteer, p.tol = self.max_steer, self.max_dsteer, self.tol
+        return p
+
+
+def linear_model(v, phi, delta, dt, L):
+    A = np.zeros((4, 4)); B = np.zeros((4, 2)); Cc = np.zeros(4)
+    lib().orc_linear_model(v, phi, delta, dt, L, _d(A), _d(B), _d(Cc))
+    return A, B, Cc
+
+
+def xy_cost_mtx(angle):
+    M = np.zeros((2, 2))
+    lib().orc_xy_cost_mtx(angle, _d(M))
+    return M
+
+
+def smooth_yaw(yaw):
+    yaw = np.ascontiguousarray(yaw, dtype=np.float64)
+    lib().orc_smooth_yaw(_d(yaw), C.c_int32(len(yaw)))
+    return yaw
+
+
+def nearest_index_in_direction(x, y, cx, cy, start, forward=True):
+    cx = np.ascontiguousarray(cx, np.float64); cy = np.ascontiguousarray(cy, np.float64)
+    return lib().orc_nearest_index_in_direction(float(x), float(y), _d(cx), _d(cy), len(cx), int(start), int(forward))
+
+
+def calc_ref_trajectory(p: MpcParams, state4, cx, cy, cyaw, dl, start_idx):
+    cx = np.ascontiguousarray(cx, np.float64); cy = np.ascontiguousarray(cy, np.float64)
+    cyaw = np.ascontiguousarray(cyaw, np.float64)
+    st = np.ascontiguousarray(state4, np.float64)
+    xref = np.zeros((4, p.T + 1)); re = np.zeros(p.T + 1, np.uint8)
+    cp = p.c()
+    s = lib().orc_calc_ref_trajectory(C.byref(cp), _d(st), _d(cx), _d(cy), _d(cyaw), C.c_int32(len(cx)), C.c_double(dl),
+                                      C.c_int32(start_idx), _d(xref), _b(re))
+    return xref, s, re
+
+
+def predict_motion(p: MpcParams, x0, oa, od):
+    x0 = np.ascontiguousarray(x0, np.float64); oa = np.ascontiguousarray(oa, np.float64); od = np.ascontiguousarray(od, np.float64)
+    xbar = np.zeros((4, p.T + 1))
+    cp = p.c()
+    lib().orc_predict_motion(C.byref(cp), _d(x0), _d(oa), _d(od), _d(xbar))
+    return xbar
+
+
+def plant_step(p: MpcParams, state4, a, delta):
+    s = np.array(state4, np.float64)
+    cp = p.c()
+    lib().orc_plant_step(C.byref(cp), _d(s), C.c_double(a), C.c_double(delta))
+    return s
+
+
+def qp_build(p: MpcParams, x0, xref, xbar, reaches_end):
+    T = p.T; n = 2 * T
+    x0 = np.ascontiguousarray(x0, np.float64); xref = np.ascontiguousarray(xref, np.float64)
+    xbar = np.ascontiguousarray(xbar, np.float64); re = np.ascontiguousarray(reaches_end, np.uint8)
+    H = np.zeros((n, n)); g = np.zeros(n); G = np.zeros((8 * T, n)); h = np.zeros(8 * T)
+    S = np.zeros((T + 1, 4, n)); c = np.zeros((T + 1, 4))
+    cp = p.c()
+    m = lib().orc_qp_build(C.byref(cp), _d(x0), _d(xref), _d(xbar), _b(re), _d(H), _d(g), _d(G), _d(h), _d(S), _d(c))
+    return H, g, G[:m], h[:m], S, c
+
+
+@dataclass
+class QpSolution:
+    status: int
+    x: np.ndarray
+    u: np.ndarray
+    lam: np.ndarray
+    iters: int
+    kkt: np.ndarray
+
+
+def qp_solve(p: MpcParams, x0, xref, xbar, reaches_end, u_warm=None) -> QpSolution:
+    T = p.T
+    x0 = np.ascontiguousarray(x0, np.float64); xref = np.ascontiguousarray(xref, np.float64)
+    xbar = np.ascontiguousarray(xbar, np.float64); re = np.ascontiguousarray(reaches_end, np.uint8)
+    x = np.zeros((4, T + 1)); u = np.zeros((2, T)); lam = np.zeros(8 * T); it = C.c_int32(0); kkt = np.zeros(4)
+    uw = None if u_warm is None else np.ascontiguousarray(u_warm, np.float64)
+    cp = p.c()
+    st = lib().orc_qp_solve(C.byref(cp), _d(x0), _d(xref), _d(xbar), _b(re), None if uw is None else _d(uw),
+                            _d(x), _d(u), _d(lam), C.byref(it), _d(kkt))
+    return QpSolution(st, x, u, lam[:8 * T - 2], it.value, kkt)
+
+
+# ---------------------------------------------------------------- search model
+class _CSearch(C.Structure):
+    _fields_ = [('n_prim', C.c_int32), ('n_obst', C.c_int32), ('tmpl_off', c_ip), ('tmpl_xy', c_dp),
+                ('last_pose', c_dp), ('edge_cost', c_dp), ('hp_off', c_ip), ('hp', c_dp)]
+
+
+class SearchModel:
+    """Flattened tables the expansion needs (primitive ids = sorted names)."""
+
+    def __init__(self, templates, last_pose, edge_cost, hp, hp_off):
+        self.tmpl_off = np.cumsum([0] + [len(t) for t in templates]).astype(np.int32)
+        self.tmpl_xy = np.ascontiguousarray(np.concatenate([np.asarray(t)[:, :2] for t in templates]), np.float64)
+        self.last_pose = np.ascontiguousarray(last_pose, np.float64)
+        self.edge_cost = np.ascontiguousarray(edge_cost, np.float64)
+        self.hp = np.ascontiguousarray(hp, np.float64)
+        self.hp_off = np.ascontiguousarray(hp_off, np.int32)
+        self.n_prim = len(templates)
+        self.n_obst = len(hp_off) - 1
+
+    def c(self):
+        return _CSearch(self.n_prim, self.n_obst, _i(self.tmpl_off), _d(self.tmpl_xy), _d(self.last_pose),
+                        _d(self.edge_cost), _i(self.hp_off), _d(self.hp))
+
+
+def expand(model: SearchModel, nodes, host_trig=True):
+    """-> nbr (n,P,3), collide (n,P). host_trig: cos/sin from numpy, as the reference computes them."""
+    nodes = np.ascontiguousarray(nodes, np.float64).reshape(-1, 3)
+    n = len(nodes)
+    nbr = np.zeros((n, model.n_prim, 3)); col = np.zeros((n, model.n_prim), np.uint8)
+    cs = np.ascontiguousarray(np.column_stack([np.cos(nodes[:, 2]), np.sin(nodes[:, 2])])) if host_trig else None
+    cm = model.c()
+    lib().orc_expand(C.byref(cm), C.c_int32(n), _d(nodes), None if cs is None else _d(cs), _d(nbr), _b(col))
+    return nbr, col
+
+
+def resample_curve(pts, dl, keep_last=True):
+    pts = np.ascontiguousarray(pts, np.float64)
+    n, stride = pts.shape
+    keep = np.zeros(n, np.int32)
+    if np.ndim(dl) == 0:
+        k = lib().orc_resample_curve(_d(pts), n, stride, None, C.c_double(float(dl)), int(keep_last), _i(keep))
+    else:
+        dlv = np.ascontiguousarray(dl, np.float64)
+        k = lib().orc_resample_curve(_d(pts), n, stride, _d(dlv), C.c_double(0.0), int(keep_last), _i(keep))
+    return pts[keep[:k]].copy()
+
+
+def predict_obstacle(six, dt, L, steps=35):
+    six = np.ascontiguousarray(six, np.float64)
+    out = np.zeros((steps, 4))
+    lib().orc_predict_obstacle(_d(six), C.c_double(dt), C.c_double(L), C.c_int32(steps), _d(out))
+    return out
+
+
+def check_collision_moving_cars(centers, radius, traj_agent, path, traj_obs, frame_window):
+    centers = np.ascontiguousarray(centers, np.float64)
+    ta = np.ascontiguousarray(traj_agent[:, :3], np.float64); pa = np.ascontiguousarray(path[:, :3], np.float64)
+    if len(traj_obs) == 0:
+        return None
+    to = np.ascontiguousarray(np.stack(traj_obs), np.float64)
+    hit = np.zeros(2)
+    idx = lib().orc_check_collision_moving_cars(_d(centers), len(centers), C.c_double(radius), _d(ta), len(ta), _d(pa), len(pa),
+                                                _d(to), to.shape[0], to.shape[1], int(frame_window), _d(hit))
+    return None if idx < 0 else (hit[0], hit[1], idx)
+
+
+def cutoff_idx(pts, x, y, radius=0.001):
+    pts = np.ascontiguousarray(pts[:, :3], np.float64)
+    return lib().orc_cutoff_idx(_d(pts), len(pts), C.c_double(x), C.c_double(y), C.c_double(radius))
+
+
+# ---------------------------------------------------------------- A* (lib/a_star.py:31-78)
+def a_star(start, is_goal, heuristic, neighbors, max_expansions=10 ** 7):
+    """Best-first search with the reference's queue semantics: entries (g+h, g, node, pred) ordered as tuples,
+    lazy deletion (skip when seen with g >= best), push only when unseen or strictly better.
+    -> (cost, path, log[(node, g, h, pred)])"""
+    heap = [(0, 0, start, start)]
+    best = {}
+    log = []
+    while heap:
+        f, g, node, pred = heapq.heappop(heap)
+        seen = best.get(node)
+        if seen is not None and g >= seen[0]:
+            continue
+        log.append((node, g, f - g, pred))
+        best[node] = (g, pred)
+        if is_goal(node):
+            path = [node]
+            while node != start:
+                path.append(pred)
+                node, pred = pred, best[pred][1]
+            return g, path[::-1], log
+        if len(log) > max_expansions:
+            break
+        for cost, nb in neighbors(node):
+            ng = g + cost
+            seen = best.get(nb)
+            if seen is None or ng < seen[0]:
+                heapq.heappush(heap, (ng + heuristic(nb), ng, nb, node))
+    raise Exception("No solution found.")

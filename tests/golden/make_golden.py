@@ -1,0 +1,481 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference, which never travels to the
+GPU box).  It imports the reference's numpy-only modules exactly as its own scripts do
+(cwd = main/scenarios, both /root/reference and /root/reference/main on sys.path) and
+records inputs/outputs of the hot-path functions listed in SURVEY.md section 8(c)
+(G1..G8).  `cvxpy` is not installable here, so an EMPTY module object is registered
+under that name purely so that `import lib.mpc` succeeds; nothing of cvxpy is emulated
+and `_linear_mpc_control` (the ECOS solve, mpc.py:138-208) is never called by this
+stage.  Stage 2 (`--stage closedloop`) drives the reference's closed loop with
+`lib.mpc._linear_mpc_control` replaced by this repo's CPU oracle QP (oracle/), to
+harvest realistic pre-QP tensors (G9: these pin QP *inputs*; QP outputs are certified
+by KKT residuals, see DESIGN.md "parity").
+
+Only DATA is written (npz/json): no reference source, bytecode or pickle is copied.
+
+usage:  python tests/golden/make_golden.py [--stage numpy|closedloop|all]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+
+def _enter_reference():
+    os.environ.setdefault('MPLBACKEND', 'Agg')
+    sys.dont_write_bytecode = True
+    sys.path[:0] = [REF, os.path.join(REF, 'main')]
+    os.chdir(os.path.join(REF, 'main', 'scenarios'))
+    if 'cvxpy' not in sys.modules:
+        sys.modules['cvxpy'] = types.ModuleType('cvxpy')  # empty: import-only placeholder
+
+
+def _savez(name, **arrays):
+    import numpy as np
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024))
+
+
+MP_SORTED = None  # primitive ids are defined by sorted name
+
+
+def stage_numpy():
+    import numpy as np
+    from lib.motion_primitive import load_motion_primitives
+    from lib.car_dimensions import BicycleModelDimensions, PriusDimensions
+    from lib.linalg import create_2d_transform_mtx, transform_2d_pts
+    from lib.maths import normalize_angle
+    from lib.obstacles import check_collision, BoxObstacle, CircleObstacle
+    from lib.trajectories import (resample_curve, calc_nearest_index_in_direction,
+                                  car_trajectory_to_collision_point_trajectories)
+    from lib.simulation import State, Simulation
+    from lib.collision_avoidance import check_collision_moving_cars, get_cutoff_curve_by_position_idx
+    from lib.moving_obstacles_prediction import MovingObstaclesPrediction
+    from lib.moving_obstacles import MovingObstacleTIntersection
+    from envs.intersection import intersection
+    import lib.motion_primitive_search as mps_base
+    import lib.motion_primitive_search_modified as mps_mod
+    import lib.motion_primitive_search_multi_lane as mps_ml
+    import lib.mpc as rmpc
+
+    rng = np.random.default_rng(20241220)
+
+    # ---------------- G1 primitives + car constants ----------------
+    prim = {}
+    meta = {}
+    for version in ('bicycle_model', 'prius'):
+        mps = load_motion_primitives(version)
+        names = sorted(mps.keys())
+        meta[version] = dict(names=names, glob_order=list(mps.keys()),
+                             total_length=[float(mps[n].total_length) for n in names],
+                             forward_speed=[float(mps[n].forward_speed) for n in names],
+                             steering_angle=[float(mps[n].steering_angle) for n in names],
+                             n_seconds=[float(mps[n].n_seconds) for n in names])
+        for n in names:
+            prim['%s/%s' % (version, n)] = np.asarray(mps[n].points, dtype=np.float64)
+    cars = {}
+    for cname, cd in (('bicycle_model', BicycleModelDimensions()), ('prius', PriusDimensions())):
+        cars[cname] = dict(L=float(cd.distance_back_to_front_wheel), radius=float(cd.radius),
+                           circle_centers=np.asarray(cd.circle_centers).tolist(),
+                           bounding_box_size=list(map(float, cd.bounding_box_size)))
+    meta['cars'] = cars
+    with open(os.path.join(HERE, 'primitives_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1)
+    _savez('primitives.npz', **prim)
+
+    # ---------------- G2 collision templates, G3 scenarios ----------------
+    bic = BicycleModelDimensions()
+    pri = PriusDimensions()
+    mps_b = load_motion_primitives('bicycle_model')
+    mps_p = load_motion_primitives('prius')
+    names_b = sorted(mps_b.keys())
+    sc0 = intersection(start_pos=4, turn_indicator=1)
+    tmpl = {}
+    for tag, mps, cd in (('bicycle_model', mps_b, bic), ('prius', mps_p, pri)):
+        s = mps_mod.MotionPrimitiveSearch(sc0, cd, mps, margin=cd.radius)
+        for n, v in s._mp_collision_points.items():
+            tmpl['%s/%s' % (tag, n)] = v
+    _savez('templates.npz', **tmpl)
+
+    scen = {}
+    for sp in (1, 2, 3, 4):
+        for ti in (1, 2, 3):
+            sc = intersection(start_pos=sp, turn_indicator=ti)
+            key = 'int_%d_%d' % (sp, ti)
+            scen[key + '/start'] = np.array(sc.start, dtype=np.float64)
+            scen[key + '/goal_point'] = np.array(sc.goal_point, dtype=np.float64)
+            scen[key + '/goal_area'] = np.array([*sc.goal_area.xy1, *sc.goal_area.xy2], dtype=np.float64)
+            scen[key + '/allowed_dtheta'] = np.array(sc.allowed_goal_theta_difference)
+            kinds, params = [], []
+            for o in sc.obstacles:
+                if isinstance(o, BoxObstacle):
+                    kinds.append(0)
+                    params.append([*o.xy1, *o.xy2, float(o.hidden)])
+                else:
+                    kinds.append(1)
+                    params.append([*o.xy_center, o.radius, 0.0, float(o.hidden)])
+            scen[key + '/obst_kind'] = np.array(kinds, dtype=np.int32)
+            scen[key + '/obst_param'] = np.array(params, dtype=np.float64)
+            for tag, cd in (('bic', bic), ('pri', pri)):
+                hps = [o.to_convex(margin=cd.radius) for o in sc.obstacles]
+                scen[key + '/hp_%s' % tag] = np.concatenate(hps, axis=0).astype(np.float64)
+                scen[key + '/hp_off'] = np.cumsum([0] + [len(h) for h in hps]).astype(np.int32)
+    _savez('scenarios.npz', **scen)
+
+    # ---------------- G5 full A* runs ----------------
+    def run_case(mod, sc, cd, mps, **kw):
+        names = sorted(mps.keys())
+        s = mod.MotionPrimitiveSearch(sc, cd, mps, margin=cd.radius, **kw)
+        cost, path, traj = s.run(debug=True)
+        seq = [names.index(s._points_to_mp_names[a, b]) for a, b in zip(path[:-1], path[1:])]
+        dbg = s.debug_data
+        return s, dict(cost=np.array(cost), path=np.array(path, dtype=np.float64),
+                       seq=np.array(seq, dtype=np.int32), traj=np.asarray(traj, dtype=np.float64),
+                       dbg_node=np.array([d.node for d in dbg], dtype=np.float64),
+                       dbg_pred=np.array([d.predecessor for d in dbg], dtype=np.float64),
+                       dbg_g=np.array([d.g for d in dbg], dtype=np.float64),
+                       dbg_h=np.array([d.h for d in dbg], dtype=np.float64))
+
+    astar = {}
+    log_nodes = []
+    paths = {}
+    for sp in (1, 2, 3, 4):
+        for ti in (1, 2, 3):
+            sc = intersection(start_pos=sp, turn_indicator=ti)
+            s, out = run_case(mps_mod, sc, bic, mps_b)
+            for k, v in out.items():
+                astar['mod_bic_%d_%d/%s' % (sp, ti, k)] = v
+            log_nodes.append(out['dbg_node'])
+            paths[(sp, ti)] = out['traj']
+    for sp, ti in ((4, 1), (1, 1), (3, 2), (2, 3)):
+        sc = intersection(start_pos=sp, turn_indicator=ti)
+        s, out = run_case(mps_base, sc, bic, mps_b)
+        for k, v in out.items():
+            astar['base_bic_%d_%d/%s' % (sp, ti, k)] = v
+    for sp, ti in ((4, 1), (1, 2), (2, 3)):
+        sc = intersection(start_pos=sp, turn_indicator=ti)
+        s, out = run_case(mps_ml, sc, bic, mps_b)
+        for k, v in out.items():
+            astar['ml_bic_%d_%d/%s' % (sp, ti, k)] = v
+    # non-default multi-lane weights exercise the obstacle / centre terms
+    sc = intersection(start_pos=4, turn_indicator=1)
+    s, out = run_case(mps_ml, sc, bic, mps_b, wh_obstacle=0.2, wh_center=0.1, wc_center=0.05)
+    for k, v in out.items():
+        astar['mlw_bic_4_1/%s' % k] = v
+    for sp, ti in ((4, 1), (1, 2)):
+        sc = intersection(start_pos=sp, turn_indicator=ti)
+        try:
+            s, out = run_case(mps_mod, sc, pri, mps_p)
+            for k, v in out.items():
+                astar['mod_pri_%d_%d/%s' % (sp, ti, k)] = v
+        except Exception as e:  # degenerate prius primitives may not reach the goal
+            print('prius case', sp, ti, 'raised', repr(e))
+    _savez('astar_runs.npz', **astar)
+
+    # ---------------- G4 neighbor_function on many nodes ----------------
+    def expand_all(s, names, hps, node):
+        """per-primitive collide flag + successor pose, with the reference's own helpers"""
+        mtx = create_2d_transform_mtx(*node)
+        flags = np.zeros(len(names), dtype=np.uint8)
+        nbr = np.full((len(names), 3), np.nan)
+        for i, n in enumerate(names):
+            pts = transform_2d_pts(node[2], mtx, s._mp_collision_points[n])[:, :2].T
+            flags[i] = any(check_collision(o, pts) for o in hps)
+            x, y, th = np.squeeze(transform_2d_pts(node[2], mtx, np.atleast_2d(s._mps[n].points[-1]))).tolist()
+            nbr[i] = (x, y, normalize_angle(th))
+        return flags, nbr
+
+    exp = {}
+    for tag, cd, mps, sp, ti in (('bic', bic, mps_b, 4, 1), ('bic1', bic, mps_b, 1, 3), ('pri', pri, mps_p, 2, 1)):
+        sc = intersection(start_pos=sp, turn_indicator=ti)
+        names = sorted(mps.keys())
+        s = mps_mod.MotionPrimitiveSearch(sc, cd, mps, margin=cd.radius)
+        n_rand = 1500
+        nodes = np.column_stack([rng.uniform(-38, 38, n_rand), rng.uniform(-38, 38, n_rand),
+                                 rng.uniform(-np.pi, np.pi, n_rand)])
+        # on-road nodes (lanes) so that many primitives are free
+        lane = rng.choice([-3.0, 3.0], 600) + rng.normal(0, 0.6, 600)
+        along = rng.uniform(-36, 36, 600)
+        horiz = rng.random(600) < 0.5
+        th = np.where(horiz, np.where(lane > 0, np.pi, 0.0), np.where(lane > 0, 0.5 * np.pi, -0.5 * np.pi))
+        th = th + rng.normal(0, 0.25, 600)
+        road = np.column_stack([np.where(horiz, along, lane), np.where(horiz, lane, along), th])
+        extra = np.concatenate(log_nodes)[:: 3] if tag != 'pri' else np.zeros((0, 3))
+        nodes = np.concatenate([nodes, road, extra, np.array([[0.0, 0.0, 0.3], [0.0, 0.0, -2.0]])])
+        fl = np.zeros((len(nodes), len(names)), dtype=np.uint8)
+        nb = np.zeros((len(nodes), len(names), 3))
+        for k, nd in enumerate(nodes):
+            fl[k], nb[k] = expand_all(s, names, s._obstacles_hp, tuple(nd.tolist()))
+        exp[tag + '/nodes'] = nodes
+        exp[tag + '/collide'] = fl
+        exp[tag + '/nbr'] = nb
+        exp[tag + '/scenario'] = np.array([sp, ti])
+        # heuristics / goal tests of the three search variants on the same nodes
+        sb = mps_base.MotionPrimitiveSearch(sc, cd, mps, margin=cd.radius)
+        sm = mps_ml.MotionPrimitiveSearch(sc, cd, mps, margin=cd.radius)
+        smw = mps_ml.MotionPrimitiveSearch(sc, cd, mps, margin=cd.radius, wh_obstacle=0.2, wh_center=0.1)
+        exp[tag + '/h_base'] = np.array([sb.distance_to_goal(tuple(n.tolist())) for n in nodes])
+        exp[tag + '/h_mod'] = np.array([s.distance_to_goal(tuple(n.tolist())) for n in nodes])
+        exp[tag + '/h_ml'] = np.array([sm.distance_to_goal(tuple(n.tolist())) for n in nodes])
+        exp[tag + '/h_mlw'] = np.array([smw.distance_to_goal(tuple(n.tolist())) for n in nodes])
+        exp[tag + '/is_goal'] = np.array([s.is_goal(tuple(n.tolist())) for n in nodes], dtype=np.uint8)
+    _savez('expand.npz', **exp)
+
+    # ---------------- G7 MPC pre-QP helpers ----------------
+    pre = {}
+    vs = np.array([-5.0, -1.0, 0.0, 0.5, 3.0, 8.0, 30 / 3.6])
+    phis = np.linspace(-3.5, 3.5, 15)
+    lin_in, lin_A, lin_B, lin_C = [], [], [], []
+    for v in vs:
+        for ph in phis:
+            for dl_ in (0.0, 0.2):
+                A, B, C = rmpc._get_linear_model_matrix(v, ph, dl_, 0.2, 2.86)
+                lin_in.append([v, ph, dl_, 0.2, 2.86]); lin_A.append(A); lin_B.append(B); lin_C.append(C)
+    pre['lin/in'] = np.array(lin_in); pre['lin/A'] = np.array(lin_A)
+    pre['lin/B'] = np.array(lin_B); pre['lin/C'] = np.array(lin_C)
+    angs = np.linspace(-4, 4, 33)
+    pre['xycost/angle'] = angs
+    pre['xycost/M'] = np.array([rmpc._get_xy_cost_mtx_for_orientation(a) for a in angs])
+
+    for T in (10, 13, 20):
+        rmpc.T = T
+        rmpc.Qf = np.diag([1.0, 1.0, 0.0, 0.5]) * T
+        c_state, c_path, c_start, c_xref, c_tind, c_re, c_oa, c_od, c_xbar = [], [], [], [], [], [], [], [], []
+        keys = sorted(paths.keys())
+        for case in range(60):
+            sp, ti = keys[case % len(keys)]
+            full = paths[(sp, ti)].copy()
+            rmpc.smooth_yaw(full[:, 2])
+            n = len(full)
+            cut = n if case % 3 else int(rng.integers(40, n))
+            path = full[:cut]
+            i0 = int(rng.integers(0, max(1, cut - 3)))
+            if case % 7 == 0:
+                i0 = max(0, cut - int(rng.integers(1, 30)))  # near the end: reaches_end rows
+            lat = rng.normal(0, 0.3)
+            yaw = path[i0, 2]
+            st = State(x=path[i0, 0] - lat * np.sin(yaw), y=path[i0, 1] + lat * np.cos(yaw),
+                       yaw=yaw + rng.normal(0, 0.05), v=float(rng.uniform(0, 30 / 3.6)) if case % 5 else 0.0)
+            start = max(0, i0 - int(rng.integers(0, 4)))
+            dl = float(np.linalg.norm(full[0, :2] - full[1, :2]))
+            try:
+                xref, tind, dref, re = rmpc._calc_ref_trajectory(st, path[:, 0], path[:, 1], path[:, 2], dl, 0.2, start, None)
+            except Exception as e:
+                print('ref case raised', repr(e)); continue
+            oa = rng.uniform(-3, 2, T); od = rng.uniform(-0.9, 0.9, T) * (rng.random() < 0.8)
+            xbar = rmpc._predict_motion([st.x, st.y, st.v, st.yaw], oa, od, xref, bic, 0.2)
+            c_state.append([st.x, st.y, st.v, st.yaw]); c_path.append((sp, ti, cut)); c_start.append(start)
+            c_xref.append(xref); c_tind.append(tind); c_re.append(re); c_oa.append(oa); c_od.append(od); c_xbar.append(xbar)
+        pre['T%d/state' % T] = np.array(c_state); pre['T%d/path' % T] = np.array(c_path, dtype=np.int32)
+        pre['T%d/start' % T] = np.array(c_start, dtype=np.int32); pre['T%d/xref' % T] = np.array(c_xref)
+        pre['T%d/target_ind' % T] = np.array(c_tind, dtype=np.int32)
+        pre['T%d/reaches_end' % T] = np.array(c_re, dtype=np.uint8)
+        pre['T%d/oa' % T] = np.array(c_oa); pre['T%d/od' % T] = np.array(c_od); pre['T%d/xbar' % T] = np.array(c_xbar)
+    rmpc.T = 13
+    rmpc.Qf = np.diag([1.0, 1.0, 0.0, 0.5]) * 13
+    for (sp, ti), tr in paths.items():
+        pre['path_%d_%d' % (sp, ti)] = tr  # raw A* trajectory (yaw NOT yet smoothed)
+    # smooth_yaw vectors
+    yy = np.concatenate([np.linspace(2.5, 3.6, 30) % (2 * np.pi) - np.pi, rng.uniform(-np.pi, np.pi, 40)])
+    pre['smooth_yaw/in'] = yy.copy()
+    pre['smooth_yaw/out'] = rmpc.smooth_yaw(yy.copy())
+    _savez('mpc_pre.npz', **pre)
+
+    # ---------------- G8 nearest index / resample / prediction / moving-car check ----------------
+    mov = {}
+    full = paths[(4, 1)]
+    ni_in, ni_out = [], []
+    for k in range(300):
+        n = len(full)
+        start = int(rng.integers(0, n))
+        if k % 10 == 0:
+            start = n - int(rng.integers(1, 4))
+        i0 = min(n - 1, start + int(rng.integers(0, 25)))
+        st = State(x=full[i0, 0] + rng.normal(0, 0.4), y=full[i0, 1] + rng.normal(0, 0.4), yaw=0.0, v=0.0)
+        try:
+            r = int(calc_nearest_index_in_direction(st, full[:, 0], full[:, 1], start_index=start, forward=True))
+        except Exception:
+            r = -1
+        ni_in.append([st.x, st.y, start]); ni_out.append(r)
+    mov['nearest/in'] = np.array(ni_in); mov['nearest/out'] = np.array(ni_out, dtype=np.int32)
+
+    rs_cases = []
+    for k, (v0, i0) in enumerate(((0.0, 0), (3.3, 100), (8.0, 250), (30 / 3.6, 10), (1.0, 600), (5.0, 655))):
+        tr = full[i0:]
+        if v0 < Simulation.MAX_SPEED:
+            rdl = np.zeros((tr.shape[0],)) + rmpc.MAX_ACCEL
+            rdl = np.cumsum(rdl) + v0
+            rdl = 0.2 * np.minimum(rdl, Simulation.MAX_SPEED)
+            out = resample_curve(tr, dl=rdl)
+        else:
+            out = resample_curve(tr, dl=0.2 * Simulation.MAX_SPEED)
+        mov['resample/%d/in' % k] = np.array([v0, i0]); mov['resample/%d/out' % k] = out
+    mov['resample/radius/out'] = resample_curve(mps_b['left3'].points.copy(), dl=bic.radius)
+
+    pr_in, pr_out = [], []
+    for k in range(40):
+        six = [rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(0, 9), rng.uniform(-np.pi, np.pi),
+               rng.uniform(-2, 2) * (k % 2), rng.uniform(-0.4, 0.4) * (k % 3 > 0)]
+        o = np.vstack(MovingObstaclesPrediction(*six, sample_time=0.2, car_dimensions=bic).state_prediction(7.0)).T
+        pr_in.append(six); pr_out.append(o)
+    mov['predict/in'] = np.array(pr_in); mov['predict/out'] = np.array(pr_out)
+
+    # scripted traffic of the stock scenario: the obstacle 6-tuples per step (scenario input data)
+    obs = [MovingObstacleTIntersection(bic, direction=1, offset=2., turning=False, speed=25 / 3.6, dt=0.2),
+           MovingObstacleTIntersection(bic, direction=-1, offset=4., turning=True, speed=25 / 3.6, dt=0.2)]
+    tape = []
+    for k in range(120):
+        tape.append([list(map(float, o.get())) for o in obs])
+        for o in obs:
+            o.step()
+    mov['traffic/tape'] = np.array(tape)  # (120, 2, 6)
+
+    # moving-car collision chain, as main/scenarios/mpc_intersection.py:103-136 sequences it
+    dl = float(np.linalg.norm(full[0, :2] - full[1, :2]))
+    margin = 4 * int(np.ceil(bic.radius / dl))
+    mc_in, mc_obs, mc_hit, mc_cut, mc_nres = [], [], [], [], []
+    for k in range(160):
+        idx = int(rng.integers(0, len(full) - 5))
+        v0 = float(rng.uniform(0, 30 / 3.6)) if k % 4 else 30 / 3.6
+        traj = full[idx:]
+        if v0 < Simulation.MAX_SPEED:
+            rdl = np.zeros((traj.shape[0],)) + rmpc.MAX_ACCEL
+            rdl = 0.2 * np.minimum(np.cumsum(rdl) + v0, Simulation.MAX_SPEED)
+            tres = resample_curve(traj, dl=rdl)
+        else:
+            tres = resample_curve(traj, dl=0.2 * Simulation.MAX_SPEED)
+        if k < 100:
+            six = np.array(tape[int(rng.integers(0, 100))])
+        else:
+            nobs = int(rng.integers(1, 8))
+            six = np.zeros((nobs, 6))
+            for j in range(nobs):
+                p = full[int(rng.integers(0, len(full)))]
+                ang = rng.uniform(-np.pi, np.pi)
+                d = rng.uniform(0, 40)
+                sp_ = rng.uniform(0, 9)
+                six[j] = [p[0] - d * np.cos(ang), p[1] - d * np.sin(ang), sp_, ang, rng.uniform(-1, 1), rng.uniform(-0.3, 0.3)]
+        trajs = [np.vstack(MovingObstaclesPrediction(*s6, sample_time=0.2, car_dimensions=bic).state_prediction(7.0)).T
+                 for s6 in six]
+        hit = check_collision_moving_cars(bic, tres, traj, trajs, frame_window=20)
+        if hit is None:
+            mc_hit.append([np.nan, np.nan, -1]); mc_cut.append(len(full))
+        else:
+            cut = get_cutoff_curve_by_position_idx(full, hit[0], hit[1]) - margin
+            cut = max(idx + 1, cut)
+            mc_hit.append([hit[0], hit[1], hit[2]]); mc_cut.append(int(cut))
+        pad = np.full((7, 6), np.nan); pad[:len(six)] = six
+        mc_in.append([idx, v0, len(six)]); mc_obs.append(pad); mc_nres.append(len(tres))
+    mov['moving/in'] = np.array(mc_in); mov['moving/obs'] = np.array(mc_obs)
+    mov['moving/hit'] = np.array(mc_hit); mov['moving/cut'] = np.array(mc_cut, dtype=np.int32)
+    mov['moving/nres'] = np.array(mc_nres, dtype=np.int32)
+    mov['moving/margin'] = np.array(margin)
+    _savez('moving.npz', **mov)
+
+
+def stage_closedloop():
+    """G9: reference closed loop (mpc_intersection.py:95-159 sequence) with the oracle QP in place of ECOS."""
+    import numpy as np
+    sys.path.insert(0, REPO)
+    from oracle import oracle_py as orc
+    from lib.motion_primitive import load_motion_primitives
+    from lib.car_dimensions import BicycleModelDimensions
+    from lib.trajectories import resample_curve, calc_nearest_index_in_direction
+    from lib.simulation import State, Simulation, HistorySimulation
+    from lib.collision_avoidance import check_collision_moving_cars, get_cutoff_curve_by_position_idx
+    from lib.moving_obstacles_prediction import MovingObstaclesPrediction
+    from lib.moving_obstacles import MovingObstacleTIntersection
+    from envs.intersection import intersection
+    from lib.motion_primitive_search_modified import MotionPrimitiveSearch
+    import lib.mpc as rmpc
+
+    out = {}
+    for T in (10, 13, 20):
+        rmpc.T = T
+        rmpc.Qf = np.diag([1.0, 1.0, 0.0, 0.5]) * T
+        params = orc.MpcParams(T=T)
+        rec = dict(x0=[], xref=[], xbar=[], re=[], oa=[], od=[], ox=[], status=[], target=[], hit=[], cut=[],
+                   state=[], ctrl=[], tidx=[])
+
+        def oracle_qp(xref, xbar, x0, dref, reaches_end, dt, car_dimensions):
+            sol = orc.qp_solve(params, np.asarray(x0, float), xref, xbar, np.asarray(reaches_end, np.uint8))
+            rec['x0'].append(np.asarray(x0, float)); rec['xref'].append(xref.copy()); rec['xbar'].append(xbar.copy())
+            rec['re'].append(np.asarray(reaches_end, np.uint8))
+            rec['status'].append(sol.status)
+            if sol.status != 0:
+                rec['oa'].append(np.full(T, np.nan)); rec['od'].append(np.full(T, np.nan)); rec['ox'].append(np.full((4, T + 1), np.nan))
+                return None, None, None, None, None, None
+            rec['oa'].append(sol.u[0].copy()); rec['od'].append(sol.u[1].copy()); rec['ox'].append(sol.x.copy())
+            return sol.u[0].copy(), sol.u[1].copy(), sol.x[0].copy(), sol.x[1].copy(), sol.x[3].copy(), sol.x[2].copy()
+
+        rmpc._linear_mpc_control = oracle_qp
+        DT = 0.2
+        mps = load_motion_primitives(version='bicycle_model')
+        cd = BicycleModelDimensions(skip_back_circle_collision_checking=False)
+        scenario = intersection(start_pos=4, turn_indicator=1)
+        moving = [MovingObstacleTIntersection(cd, direction=1, offset=2., turning=False, speed=25 / 3.6, dt=DT),
+                  MovingObstacleTIntersection(cd, direction=-1, offset=4., turning=True, speed=25 / 3.6, dt=DT)]
+        search = MotionPrimitiveSearch(scenario, cd, mps, margin=cd.radius)
+        _, _, full = search.run(debug=False)
+        dl = np.linalg.norm(full[0, :2] - full[1, :2])
+        mpc = rmpc.MPC(cx=full[:, 0], cy=full[:, 1], cyaw=full[:, 2], dl=dl, dt=DT, car_dimensions=cd)
+        state = State(x=full[0, 0], y=full[0, 1], yaw=full[0, 2], v=0.0)
+        sim = HistorySimulation(car_dimensions=cd, sample_time=DT, initial_state=state)
+        margin = 4 * int(np.ceil(cd.radius / dl))
+        tidx = 0
+        tmp = None
+        for i in range(400):
+            if mpc.is_goal(state):
+                break
+            if tmp is None or np.any(tmp[tidx, :] != tmp[-1, :]):
+                tidx = calc_nearest_index_in_direction(state, full[:, 0], full[:, 1], start_index=tidx, forward=True)
+            tres = traj = full[tidx:]
+            if state.v < Simulation.MAX_SPEED:
+                rdl = np.zeros((tres.shape[0],)) + rmpc.MAX_ACCEL
+                rdl = DT * np.minimum(np.cumsum(rdl) + state.v, Simulation.MAX_SPEED)
+                tres = resample_curve(tres, dl=rdl)
+            else:
+                tres = resample_curve(tres, dl=DT * Simulation.MAX_SPEED)
+            trajs = [np.vstack(MovingObstaclesPrediction(*o.get(), sample_time=DT, car_dimensions=cd).state_prediction(7.)).T
+                     for o in moving]
+            hit = check_collision_moving_cars(cd, tres, traj, trajs, frame_window=20)
+            if hit is not None:
+                cut = get_cutoff_curve_by_position_idx(full, hit[0], hit[1]) - margin
+                cut = max(tidx + 1, cut)
+                tmp = full[:cut]
+                rec['hit'].append([hit[0], hit[1], hit[2]]); rec['cut'].append(int(cut))
+            else:
+                tmp = full
+                rec['hit'].append([np.nan, np.nan, -1]); rec['cut'].append(len(full))
+            rec['state'].append([state.x, state.y, state.v, state.yaw]); rec['tidx'].append(int(tidx))
+            mpc.set_trajectory_fromarray(tmp)
+            delta, acc = mpc.step(state)
+            rec['target'].append(int(mpc.target_ind)); rec['ctrl'].append([delta, acc])
+            for o in moving:
+                o.step()
+            state = sim.step(a=acc, delta=delta, xref_deviation=mpc.get_current_xref_deviation())
+        print('T=%d closed loop: %d steps, goal=%s' % (T, i, mpc.is_goal(state)))
+        for k, v in rec.items():
+            out['T%d/%s' % (T, k)] = np.array(v)
+        out['T%d/full' % T] = full  # yaw column already smoothed in place by MPC.__init__
+        out['T%d/steps' % T] = np.array(i)
+    _savez('closedloop.npz', **out)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--stage', default='numpy', choices=['numpy', 'closedloop', 'all'])
+    a = ap.parse_args()
+    _enter_reference()
+    if a.stage in ('numpy', 'all'):
+        stage_numpy()
+    if a.stage in ('closedloop', 'all'):
+        stage_closedloop()
