@@ -1,0 +1,139 @@
+/*
+ * mpcx.h -- C ABI of libmpcx.so, the MI355X (gfx950) implementation of the per-timestep hot path of
+ * SaeedRahmani/MPC_for_AV_at_Intersection.  The reference has no FFI of its own (pure Python); each entry
+ * point below names the reference function(s) it replaces (paths relative to /root/reference/main) -- the
+ * Python objects in mpc_for_av_at_intersection_amd/ present the reference's call surface on top of this ABI,
+ * and INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns int32 status: 0 = OK, <0 = error
+ *     (MPCX_E_*; text via mpcx_last_error()).  Solver non-convergence is per-instance DATA (status[] array),
+ *     never an error code -- mirroring lib/mpc.py:196-206.
+ *   - every array argument is a DEVICE pointer (HIP global memory, e.g. torch tensor.data_ptr()), float64 /
+ *     int32 / uint8, C-contiguous, batch as the slowest index.  Caller owns every buffer.
+ *   - launches go to the HIP stream given at mpcx_create (NULL = default stream); calls are asynchronous
+ *     with respect to the host exactly like a kernel launch, the caller synchronises the stream.
+ *   - one mpcx_ctx per host thread / stream; a ctx is not re-entrant.
+ */
+#ifndef MPCX_H
+#define MPCX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCX_T_MAX 32            /* horizon capacity (2T lanes of one wavefront) */
+#define MPCX_MAX_PRIM 16         /* motion primitives per search model */
+#define MPCX_MAX_OBS 16          /* moving obstacles seen by one ego */
+#define MPCX_PRED_STEPS_MAX 64   /* prediction horizon frames */
+#define MPCX_MAX_REMAINING 1024  /* path points ahead of an agent handled by mpcx_interaction_batch */
+#define MPCX_EGO_FRAMES_MAX 128  /* resampled ego poses handled by mpcx_interaction_batch */
+
+enum {
+    MPCX_OK = 0,
+    MPCX_E_INVALID = -1,   /* bad argument (null pointer, size out of range, unsupported horizon) */
+    MPCX_E_LAUNCH = -2,    /* HIP launch / runtime failure */
+    MPCX_E_NODEVICE = -3   /* no usable GPU */
+};
+
+/* per-instance solver status (status[] outputs) */
+enum { MPCX_QP_OPTIMAL = 0, MPCX_QP_MAXITER = 1, MPCX_QP_INFEASIBLE = 2, MPCX_QP_NUMERIC = 3 };
+
+typedef struct mpcx_ctx mpcx_ctx;
+
+/* lib/mpc.py:13-36 (config/mpc_config.json) + lib/simulation.py:23-25 + car_dimensions.py:82-107 */
+typedef struct {
+    int32_t T;          /* horizon, 1..MPCX_T_MAX */
+    int32_t max_iter;   /* interior-point iteration cap */
+    double dt, L;
+    double w_perp, w_para;
+    double R[2], Rd[2], Q_v_yaw[2];
+    double Qf[4];       /* ALREADY multiplied by T (mpc.py:25) */
+    double R_end[2];    /* diag(10,10) (mpc.py:178) */
+    double max_speed, min_speed, max_accel, max_decel, max_steer, max_dsteer /* rad/s */;
+    double tol;         /* KKT tolerance (relative) */
+} mpcx_mpc_params;
+
+mpcx_ctx *mpcx_create(int32_t device, void *hip_stream);
+void mpcx_destroy(mpcx_ctx *ctx);
+const char *mpcx_last_error(mpcx_ctx *ctx);
+const char *mpcx_version(void);
+int32_t mpcx_set_mpc_params(mpcx_ctx *ctx, const mpcx_mpc_params *p);
+
+/* ---- lib/mpc.py:138-208 `_linear_mpc_control` (incl. :58-79 `_get_linear_model_matrix`, :129-135): the QP.
+ * Solves B independent problems.  Outputs laid out as the reference's x.value / u.value:
+ * x_out[b,0..3,:] = (x, y, v, yaw), u_out[b,0,:] = accel, u_out[b,1,:] = steer.  u_warm may be NULL (zeros).
+ * status[b] != 0  <=>  the reference's "Cannot solve mpc" branch (outputs then hold the last iterate).
+ * kkt[b,:] = (stationarity inf-norm, primal residual inf-norm, mean complementarity, unused). */
+int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B,
+                            const double *x0 /*B,4: x,y,v,yaw*/, const double *xref /*B,4,T+1*/,
+                            const double *xbar /*B,4,T+1*/, const uint8_t *reaches_end /*B,T+1*/,
+                            const double *u_warm /*B,2,T or NULL*/,
+                            double *x_out /*B,4,T+1*/, double *u_out /*B,2,T*/,
+                            int32_t *status /*B*/, int32_t *iters /*B*/, double *kkt /*B,4*/);
+
+/* ---- lib/mpc.py:86-109 `_calc_ref_trajectory` (+ trajectories.py:100-126) and :112-126 `_predict_motion`
+ * (+ simulation.py:35-47, bicycle/main.py:28-41).  Paths are ragged: instance b tracks points
+ * [path_off[b], path_off[b]+path_len[b]) of path_xyyaw (rows x,y,yaw; yaw already smooth_yaw'ed);
+ * path_len[b] is the CURRENT (possibly cut) length, as after MPC.set_trajectory_fromarray.
+ * target_ind is in-out (mpc.py:226).  target_ind[b] = -1 on the reference's Exception("something wrong"). */
+int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double *state /*B,4: x,y,v,yaw*/,
+                               const double *u_warm /*B,2,T or NULL*/,
+                               const double *path_xyyaw /*npts,3*/, const int32_t *path_off /*B*/,
+                               const int32_t *path_len /*B*/, double dl, int32_t *target_ind /*B in-out*/,
+                               double *xref /*B,4,T+1*/, uint8_t *reaches_end /*B,T+1*/, double *xbar /*B,4,T+1*/);
+
+/* ---- lib/motion_primitive_search.py:87-121 `neighbor_function` (+ obstacles.py:157-176 `check_collision`,
+ * linalg.py:4-54, maths.py:4-10).  Model tables are copied to the device once by mpcx_search_model_create
+ * (HOST pointers there).  primitive id = index in the arrays given (callers use sorted names). */
+typedef struct mpcx_search_model mpcx_search_model;
+mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_prim,
+                                            const int32_t *tmpl_off /*n_prim+1*/, const double *tmpl_xy /*npts,2*/,
+                                            const double *last_pose /*n_prim,3*/, const double *edge_cost /*n_prim*/,
+                                            int32_t n_obst, const int32_t *hp_off /*n_obst+1*/, const double *hp /*rows,3*/);
+void mpcx_search_model_destroy(mpcx_search_model *m);
+int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, int32_t n_nodes, const double *nodes /*n,3*/,
+                          double *nbr /*n,P,3*/, double *cost /*n,P*/, uint8_t *collide /*n,P*/);
+
+/* ---- lib/collision_avoidance.py:66-119 `check_collision_moving_cars` + `get_cutoff_curve_by_position_idx`,
+ * lib/moving_obstacles_prediction.py:21-47, trajectories.py:58-86 `resample_curve`, and the caller sequence
+ * scenarios/mpc_intersection.py:103-136.  P independent problems (one ego each).  Moving obstacles live in a
+ * pool obs6[NOBS,6] of 6-tuples (x, y, v, yaw, a, steer) -- what MovingObstacle*.get() returns,
+ * mpc_intersection.py:119-122; each is predicted once.  Problem p sees obstacles
+ * obs_off[p] .. obs_off[p]+obs_cnt[p]-1 of the pool except index obs_skip[p] (-1 = none): an N-agent instance
+ * puts its N agents in the pool and every agent skips itself.
+ * path_cs holds cos/sin of the path yaw column (the host computes them once per path with the same libm the
+ * reference uses, so disc centres match trajectories.py:11-37 bit for bit).
+ * Outputs: traj_idx (in-out, the scenario's traj_agent_idx), hit_idx (-1 = None, else index on the remaining
+ * path; -2 = limits exceeded: more than MPCX_MAX_REMAINING path points ahead or MPCX_EGO_FRAMES_MAX resampled
+ * poses; -3 = the reference's Exception("something wrong")), hit_xy, cut_len (length of the tmp_trajectory
+ * handed to MPC.set_trajectory_fromarray). */
+typedef struct {
+    int32_t pred_steps;      /* len(arange(0, TIME_HORIZON, DT)) = 35 */
+    int32_t frame_window;    /* 20 */
+    int32_t cutoff_margin;   /* EXTRA_CUTOFF_MARGIN = 4*ceil(radius/dl) */
+    int32_t reserved;
+    double dt, L, radius;
+    double circle_centers[4]; /* (x,y) of the 2 discs, car_dimensions.py:61-79 */
+    double max_accel, max_speed;
+} mpcx_interaction_params;
+int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip, int32_t P,
+                               const double *state /*P,4*/,
+                               const double *path_xyyaw /*npts,3*/, const double *path_cs /*npts,2: cos(yaw),sin(yaw)*/,
+                               const int32_t *path_off /*P*/, const int32_t *path_len /*P (full length)*/,
+                               const int32_t *prev_cut_len /*P or NULL*/,
+                               int32_t n_obs_pool, const double *obs6 /*NOBS,6*/, const int32_t *obs_off /*P*/,
+                               const int32_t *obs_cnt /*P*/, const int32_t *obs_skip /*P or NULL*/,
+                               int32_t *traj_idx /*P in-out*/, int32_t *hit_idx /*P*/, double *hit_xy /*P,2*/,
+                               int32_t *cut_len /*P*/);
+
+/* ---- plant: lib/simulation.py:35-47 `Simulation.step` on B states with the first control of each solution;
+ * failed instances (status != 0) get (previous steer, MAX_DECEL) as MPC.step does (mpc.py:294-297). */
+int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state /*B,4 in-out*/, const double *u /*B,2,T*/,
+                              const int32_t *status /*B or NULL*/, double *applied /*B,2 in-out: (steer, accel)*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

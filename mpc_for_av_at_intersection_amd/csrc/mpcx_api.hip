@@ -1,0 +1,61 @@
+// mpcx_api.hip -- context, parameters and error plumbing of libmpcx.so (see include/mpcx.h).
+#include "mpcx_common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+int32_t mpcx_fail(mpcx_ctx *ctx, int32_t code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+int32_t mpcx_check_launch(mpcx_ctx *ctx, const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mpcx_fail(ctx, MPCX_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return MPCX_OK;
+}
+
+extern "C" {
+
+const char *mpcx_version(void) { return "mpcx 0.1 (gfx950)"; }
+
+mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    mpcx_ctx *c = new (std::nothrow) mpcx_ctx();
+    if (!c) return nullptr;
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    c->have_mpc = false;
+    c->pred = nullptr;
+    c->pred_cap = 0;
+    c->err[0] = 0;
+    return c;
+}
+
+void mpcx_destroy(mpcx_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->pred) (void)hipFree(ctx->pred);
+    delete ctx;
+}
+
+const char *mpcx_last_error(mpcx_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int32_t mpcx_set_mpc_params(mpcx_ctx *ctx, const mpcx_mpc_params *p) {
+    if (!ctx || !p) return MPCX_E_INVALID;
+    if (p->T < 1 || p->T > MPCX_T_MAX) return mpcx_fail(ctx, MPCX_E_INVALID, "horizon T=%d outside 1..%d", p->T, MPCX_T_MAX);
+    if (!(p->dt > 0) || !(p->L > 0) || p->max_iter < 1 || !(p->tol > 0))
+        return mpcx_fail(ctx, MPCX_E_INVALID, "dt, L, tol must be positive and max_iter >= 1");
+    ctx->mpc = *p;
+    ctx->have_mpc = true;
+    return MPCX_OK;
+}
+
+}  // extern "C"

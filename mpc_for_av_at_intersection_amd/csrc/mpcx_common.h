@@ -1,0 +1,124 @@
+// mpcx_common.h -- shared device helpers for the libmpcx.so kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mpcx.h"
+
+struct mpcx_ctx {
+    int device;
+    hipStream_t stream;
+    mpcx_mpc_params mpc;
+    bool have_mpc;
+    double *pred;        // scratch: predicted obstacle disc centres [NOBS][steps][2 discs][2]
+    size_t pred_cap;     // capacity of pred in doubles
+    char err[256];
+};
+
+int32_t mpcx_fail(mpcx_ctx *ctx, int32_t code, const char *fmt, ...);
+int32_t mpcx_check_launch(mpcx_ctx *ctx, const char *what);
+
+namespace mpcx {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ double rdlane(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+// 1/d and 1/sqrt(d): hardware seed + two Newton steps (full double accuracy, not correctly rounded)
+__device__ __forceinline__ double frcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double frsq(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, WAVE));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmin(v, __shfl_xor(v, d, WAVE));
+    return v;
+}
+// inclusive prefix sum over lanes (lane i gets sum of lanes 0..i)
+__device__ __forceinline__ double scan_up(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        double t = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// inclusive suffix sum over lanes (lane i gets sum of lanes i..63)
+__device__ __forceinline__ double scan_down(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        double t = __shfl_down(v, d, WAVE);
+        if (lane + d < WAVE) v += t;
+    }
+    return v;
+}
+
+// lexicographic (distance, index) minimum over the wave
+__device__ __forceinline__ void wave_argmin(double &d, int &i) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        double od = __shfl_xor(d, s, WAVE);
+        int oi = __shfl_xor(i, s, WAVE);
+        bool take = (od < d) || (od == d && oi < i);
+        d = take ? od : d;
+        i = take ? oi : i;
+    }
+}
+
+__device__ __forceinline__ double pt_dist(const double *path, int idx, double x, double y) {
+    double dx = __dadd_rn(path[3 * idx], -x), dy = __dadd_rn(path[3 * idx + 1], -y);
+    return __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+}
+
+// trajectories.py:100-126 on path[start .. n) ; returns absolute index or -1 ("something wrong")
+__device__ inline int nearest_index_in_direction(const double *path, int n, int start, double x, double y, int lane) {
+    const int len = n - start;
+    if (len <= 1) return start;
+    if (len == 2) return start + 1;
+    int bi[3];
+    double bd[3];
+    // three passes of (distance, index)-argmin == the three smallest in ascending order, ties by lower index
+#pragma unroll
+    for (int pass = 0; pass < 3; pass++) {
+        double d = INFINITY;
+        int ix = 0x7fffffff;
+        for (int i = lane; i < len; i += WAVE) {
+            bool skip = (pass >= 1 && i == bi[0]) || (pass >= 2 && i == bi[1]);
+            double di = pt_dist(path, start + i, x, y);
+            bool take = !skip && ((di < d) || (di == d && i < ix));
+            d = take ? di : d;
+            ix = take ? i : ix;
+        }
+        wave_argmin(d, ix);
+        bd[pass] = d;
+        bi[pass] = ix;
+    }
+    (void)bd;
+    if (abs(bi[1] - bi[2]) == 2) return bi[0] + start;
+    if (abs(bi[0] - bi[1]) == 1) return max(bi[0], bi[1]) + start;
+    return -1;
+}
+
+}  // namespace mpcx

@@ -1,0 +1,152 @@
+// mpcx_expand.hip -- batched motion-primitive successor generation with half-plane collision culling.
+//
+// Replaces lib/motion_primitive_search.py:87-121 `neighbor_function` (identical in _modified.py:101-135),
+// lib/obstacles.py:157-176 `check_collision`, lib/linalg.py:4-54 and lib/maths.py:4-10
+// (paths relative to /root/reference/main).  One thread per (node, primitive) pair; obstacle half-planes and
+// primitive collision templates are staged once per block in LDS (read as wave-uniform broadcasts), successor
+// poses/costs/flags are written as contiguous (node, primitive) records so stores coalesce.
+// Row order inside an obstacle is kept (axis-aligned rows come first for both boxes and the circle octagons,
+// obstacles.py:87-90,140-148), so the per-point early-out acts as an exact bounding-box cull.
+#include "mpcx_common.h"
+#include <vector>
+
+struct mpcx_search_model {
+    int n_prim, n_obst, n_pts, n_rows;
+    int32_t *d_tmpl_off, *d_hp_off;
+    double *d_tmpl_xy, *d_last_pose, *d_edge_cost, *d_hp;
+};
+
+namespace mpcx {
+
+constexpr int EXP_MAX_ROWS = 512;   // half-plane rows staged in LDS
+constexpr int EXP_MAX_PTS = 512;    // template points staged in LDS
+constexpr int EXP_MAX_OBST = 128;
+
+struct ExpandArgs {
+    int n_prim, n_obst, n_pts, n_rows, n_nodes;
+    const int32_t *tmpl_off, *hp_off;
+    const double *tmpl_xy, *last_pose, *edge_cost, *hp, *nodes;
+    double *nbr, *cost;
+    uint8_t *collide;
+};
+
+// maths.py:4-10 (python float %: result takes the sign of the divisor)
+__device__ __forceinline__ double normalize_angle(double th) {
+    const double tau = 6.283185307179586, pi = 3.141592653589793;
+    th = fmod(th, tau);
+    if (th < 0) th += tau;
+    if (th >= tau) th = 0.0;
+    if (th >= pi) th -= tau;
+    return th;
+}
+
+__global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) {
+    __shared__ double s_hp[EXP_MAX_ROWS * 3];
+    __shared__ double s_xy[EXP_MAX_PTS * 2];
+    __shared__ int32_t s_hoff[EXP_MAX_OBST + 1];
+    __shared__ int32_t s_toff[MPCX_MAX_PRIM + 1];
+    for (int i = threadIdx.x; i < a.n_rows * 3; i += blockDim.x) s_hp[i] = a.hp[i];
+    for (int i = threadIdx.x; i < a.n_pts * 2; i += blockDim.x) s_xy[i] = a.tmpl_xy[i];
+    for (int i = threadIdx.x; i <= a.n_obst; i += blockDim.x) s_hoff[i] = a.hp_off[i];
+    for (int i = threadIdx.x; i <= a.n_prim; i += blockDim.x) s_toff[i] = a.tmpl_off[i];
+    __syncthreads();
+
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)a.n_nodes * a.n_prim;
+    if (gid >= total) return;
+    const int node = (int)(gid / a.n_prim), k = (int)(gid % a.n_prim);
+    const double x = a.nodes[3 * node], y = a.nodes[3 * node + 1], th = a.nodes[3 * node + 2];
+    double s, c;
+    sincos(th, &s, &c);
+    const bool rot_only = (x == 0.0 && y == 0.0);     // linalg.py:13-17
+    const double tx = rot_only ? 0.0 : x, ty = rot_only ? 0.0 : y;
+
+    // world-space collision points of this primitive (<= 32 kept in registers would spill; recompute per obstacle)
+    const int p0 = s_toff[k], p1 = s_toff[k + 1];
+    bool hit = false;
+    for (int o = 0; o < a.n_obst && !hit; o++) {
+        const int r0 = s_hoff[o], r1 = s_hoff[o + 1];
+        for (int i = p0; i < p1 && !hit; i++) {
+            const double px = s_xy[2 * i], py = s_xy[2 * i + 1];
+            // (x*m0 + y*m1) + t with the first product rounded and the second fused: the order OpenBLAS uses for N>=2 rows
+            const double wx = __dadd_rn(fma(py, -s, __dmul_rn(px, c)), tx);
+            const double wy = __dadd_rn(fma(py, c, __dmul_rn(px, s)), ty);
+            bool inside = true;
+            for (int r = r0; r < r1; r++) {
+                const double v = __dadd_rn(__dadd_rn(__dmul_rn(s_hp[3 * r], wx), __dmul_rn(s_hp[3 * r + 1], wy)), s_hp[3 * r + 2]);
+                if (!(v <= 0.0)) { inside = false; break; }
+            }
+            hit = inside;
+        }
+    }
+    const double lx = a.last_pose[3 * k], ly = a.last_pose[3 * k + 1], lt = a.last_pose[3 * k + 2];
+    double *o3 = a.nbr + (size_t)gid * 3;
+    o3[0] = __dadd_rn(fma(lx, c, __dmul_rn(ly, -s)), tx);      // N==1 row: fma(x, m0, y*m1) + t
+    o3[1] = __dadd_rn(fma(lx, s, __dmul_rn(ly, c)), ty);
+    o3[2] = normalize_angle(__dadd_rn(lt, th));
+    a.cost[gid] = a.edge_cost[k];
+    a.collide[gid] = hit ? 1 : 0;
+}
+
+}  // namespace mpcx
+
+template <typename Tp>
+static Tp *to_device(const Tp *h, size_t n) {
+    Tp *d = nullptr;
+    if (hipMalloc((void **)&d, (n ? n : 1) * sizeof(Tp)) != hipSuccess) return nullptr;
+    if (n && hipMemcpy(d, h, n * sizeof(Tp), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    return d;
+}
+
+extern "C" mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_prim, const int32_t *tmpl_off,
+                                                       const double *tmpl_xy, const double *last_pose,
+                                                       const double *edge_cost, int32_t n_obst,
+                                                       const int32_t *hp_off, const double *hp) {
+    if (!ctx) return nullptr;
+    if (n_prim < 1 || n_prim > MPCX_MAX_PRIM || n_obst < 0 || n_obst > mpcx::EXP_MAX_OBST || !tmpl_off || !tmpl_xy ||
+        !last_pose || !edge_cost || !hp_off || (n_obst > 0 && !hp)) {
+        mpcx_fail(ctx, MPCX_E_INVALID, "search_model_create: bad sizes or null tables");
+        return nullptr;
+    }
+    const int n_pts = tmpl_off[n_prim], n_rows = hp_off[n_obst];
+    if (n_pts > mpcx::EXP_MAX_PTS || n_rows > mpcx::EXP_MAX_ROWS || n_pts < 0 || n_rows < 0) {
+        mpcx_fail(ctx, MPCX_E_INVALID, "search_model_create: %d template points / %d half-plane rows exceed %d / %d",
+                  n_pts, n_rows, mpcx::EXP_MAX_PTS, mpcx::EXP_MAX_ROWS);
+        return nullptr;
+    }
+    mpcx_search_model *m = new mpcx_search_model();
+    m->n_prim = n_prim; m->n_obst = n_obst; m->n_pts = n_pts; m->n_rows = n_rows;
+    m->d_tmpl_off = to_device(tmpl_off, n_prim + 1);
+    m->d_hp_off = to_device(hp_off, n_obst + 1);
+    m->d_tmpl_xy = to_device(tmpl_xy, (size_t)n_pts * 2);
+    m->d_last_pose = to_device(last_pose, (size_t)n_prim * 3);
+    m->d_edge_cost = to_device(edge_cost, n_prim);
+    m->d_hp = to_device(hp, (size_t)n_rows * 3);
+    if (!m->d_tmpl_off || !m->d_hp_off || !m->d_tmpl_xy || !m->d_last_pose || !m->d_edge_cost || !m->d_hp) {
+        mpcx_fail(ctx, MPCX_E_LAUNCH, "search_model_create: device allocation failed");
+        mpcx_search_model_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+extern "C" void mpcx_search_model_destroy(mpcx_search_model *m) {
+    if (!m) return;
+    (void)hipFree(m->d_tmpl_off); (void)hipFree(m->d_hp_off); (void)hipFree(m->d_tmpl_xy);
+    (void)hipFree(m->d_last_pose); (void)hipFree(m->d_edge_cost); (void)hipFree(m->d_hp);
+    delete m;
+}
+
+extern "C" int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, int32_t n_nodes, const double *nodes,
+                                     double *nbr, double *cost, uint8_t *collide) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (!m || n_nodes < 0 || !nodes || !nbr || !cost || !collide)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "expand_batch: null pointer or negative node count");
+    if (n_nodes == 0) return MPCX_OK;
+    mpcx::ExpandArgs a{m->n_prim, m->n_obst, m->n_pts, m->n_rows, n_nodes, m->d_tmpl_off, m->d_hp_off,
+                       m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_hp, nodes, nbr, cost, collide};
+    const long long total = (long long)n_nodes * m->n_prim;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(mpcx::expand_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    return mpcx_check_launch(ctx, "expand_kernel");
+}

@@ -1,0 +1,306 @@
+// mpcx_interaction.hip -- ego-vs-moving-cars conflict search and reference-path cut, batched.
+//
+// Replaces (paths relative to /root/reference/main):
+//   lib/moving_obstacles_prediction.py:21-47  MovingObstaclesPrediction.state_prediction -> predict_kernel
+//   scenarios/mpc_intersection.py:103-116     nearest index on the full path + ego prediction resampling
+//   lib/trajectories.py:58-86                 resample_curve (vector dl)
+//   lib/collision_avoidance.py:66-104         check_collision_moving_cars
+//   lib/collision_avoidance.py:107-119 + mpc_intersection.py:129-136  cut-off index
+// One wavefront per ego.  The reference flattens (frame, agent disc, obstacle x frame-offset, obstacle disc)
+// into one pair table and takes the first row within 2*radius; here the obstacle disc positions (<= 16*64*2)
+// are first culled exactly against the bounding box of the ego's predicted discs, survivors are tested
+// against every frame whose +-frame_window shift reaches them, and the FIRST ROW IN THE REFERENCE'S ORDER is
+// recovered as the minimum of an integer key over all hits (bit-exact index outputs).
+#include "mpcx_common.h"
+
+namespace mpcx {
+
+struct PredArgs {
+    mpcx_interaction_params ip;
+    int n;
+    const double *obs6;
+    double *pred;    // [n][steps][2][2]
+};
+
+// moving_obstacles_prediction.py:21-28: v is updated BEFORE yaw; disc centres as trajectories.py:11-37
+__global__ __launch_bounds__(256) void predict_kernel(PredArgs a) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= a.n) return;
+    const double *s6 = a.obs6 + 6 * (size_t)o;
+    double x = s6[0], y = s6[1], v = s6[2], yaw = s6[3];
+    const double acc = s6[4], tn = tan(s6[5]);
+    const double dt = a.ip.dt;
+    double s, c;
+    sincos(yaw, &s, &c);
+    double *out = a.pred + (size_t)o * a.ip.pred_steps * 4;
+    for (int k = 0; k < a.ip.pred_steps; k++) {
+        x = __dadd_rn(x, __dmul_rn(__dmul_rn(v, c), dt));
+        y = __dadd_rn(y, __dmul_rn(__dmul_rn(v, s), dt));
+        v = __dadd_rn(v, __dmul_rn(acc, dt));
+        yaw = __dadd_rn(yaw, __dmul_rn(__dmul_rn(__ddiv_rn(v, a.ip.L), tn), dt));
+        sincos(yaw, &s, &c);
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const double cx = a.ip.circle_centers[2 * d], cy = a.ip.circle_centers[2 * d + 1];
+            out[4 * k + 2 * d] = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), x);
+            out[4 * k + 2 * d + 1] = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), y);
+        }
+    }
+}
+
+struct InterArgs {
+    mpcx_interaction_params ip;
+    int P;
+    const double *state, *path, *path_cs;
+    const int32_t *path_off, *path_len, *prev_cut;
+    const double *pred;
+    const int32_t *obs_off, *obs_cnt, *obs_skip;
+    int32_t *traj_idx, *hit_idx;
+    double *hit_xy;
+    int32_t *cut_len;
+};
+
+__device__ __forceinline__ double dist2d(double ax, double ay, double bx, double by) {
+    const double dx = __dadd_rn(ax, -bx), dy = __dadd_rn(ay, -by);
+    return __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+}
+__device__ __forceinline__ long long wave_min_ll(long long v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { long long o = __shfl_xor(v, s, WAVE); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { int o = __shfl_xor(v, s, WAVE); v = o < v ? o : v; }
+    return v;
+}
+
+constexpr int MAXREM = MPCX_MAX_REMAINING;
+constexpr int MAXF = MPCX_EGO_FRAMES_MAX;
+constexpr int MAXCAND = MPCX_MAX_OBS * MPCX_PRED_STEPS_MAX * 2;
+
+__global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
+    __shared__ double s_cum[MAXREM];
+    __shared__ int s_keep[MAXF];
+    __shared__ double s_ego[MAXF][4];     // ego disc centres per kept pose: (x0,y0,x1,y1)
+    __shared__ int s_cand[MAXCAND];       // surviving obstacle disc ids: (o*steps + g)*2 + co
+    __shared__ int s_cnt;
+
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const mpcx_interaction_params &ip = a.ip;
+    const double *path = a.path + 3 * (size_t)a.path_off[p];
+    const double *pcs = a.path_cs + 2 * (size_t)a.path_off[p];
+    const int len = a.path_len[p];
+    const double x = a.state[4 * p], y = a.state[4 * p + 1], v = a.state[4 * p + 2];
+    const double md = 2.0 * ip.radius;
+    const int steps = ip.pred_steps, w = ip.frame_window;
+
+    // ---- mpc_intersection.py:103-105: advance traj_agent_idx unless the previous tmp_trajectory collapsed onto it
+    int tidx = a.traj_idx[p];
+    bool advance = true;
+    if (a.prev_cut && a.prev_cut[p] > 0) {
+        const int last = a.prev_cut[p] - 1;
+        advance = (path[3 * tidx] != path[3 * last]) || (path[3 * tidx + 1] != path[3 * last + 1]) ||
+                  (path[3 * tidx + 2] != path[3 * last + 2]);
+    }
+    if (advance) tidx = nearest_index_in_direction(path, len, tidx, x, y, lane);
+    if (tidx < 0) {
+        if (lane == 0) { a.hit_idx[p] = -3; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        return;
+    }
+    if (lane == 0) a.traj_idx[p] = tidx;
+    const double *rem = path + 3 * (size_t)tidx;      // trajectory = trajectory_full[traj_agent_idx:]
+    const double *rcs = pcs + 2 * (size_t)tidx;
+    const int n = len - tidx;
+    const int nobs = a.obs_cnt[p] - ((a.obs_skip && a.obs_skip[p] >= 0) ? 1 : 0);
+    if (n > MAXREM || nobs > MPCX_MAX_OBS) {
+        if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        return;
+    }
+    if (nobs <= 0) {    // collision_avoidance.py:69-70
+        if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        return;
+    }
+
+    // ---- mpc_intersection.py:110-116 + trajectories.py:72-86: ego prediction = resample_curve(trajectory, dl_k)
+    for (int i = lane; i < n; i += WAVE)
+        s_cum[i] = (i == 0) ? 0.0 : dist2d(rem[3 * i], rem[3 * i + 1], rem[3 * (i - 1)], rem[3 * (i - 1) + 1]);
+    __syncthreads();
+    if (lane == 0) {                      // np.cumsum: strictly sequential adds
+        double c = 0.0;
+        for (int i = 0; i < n; i++) { c = __dadd_rn(c, s_cum[i]); s_cum[i] = c; }
+        s_cnt = 0;
+    }
+    __syncthreads();
+    const bool accel_phase = v < ip.max_speed;
+    const double dl_const = __dmul_rn(ip.dt, ip.max_speed);
+    int base = 0;
+    bool overflow = false;
+    for (int i0 = 0; i0 < n; i0 += WAVE) {
+        const int i = i0 + lane;
+        bool keep = false;
+        if (i < n) {
+            auto qof = [&](int j) -> long long {
+                double dl = dl_const;
+                if (accel_phase) {
+                    const double r = __dadd_rn(__dmul_rn(ip.max_accel, (double)(j + 1)), v);   // cumsum of equal terms (exact for 2.0) + v
+                    dl = __dmul_rn(ip.dt, fmin(r, ip.max_speed));
+                }
+                return (long long)floor(__ddiv_rn(s_cum[j], dl));
+            };
+            keep = (i == 0) || (i == n - 1) || (qof(i) - qof(i - 1) >= 1);
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) { if (pos < MAXF) s_keep[pos] = i; else overflow = true; }
+        base += __popcll(m);
+    }
+    const int na = base;
+    if (na > MAXF) {
+        if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        return;
+    }
+    (void)overflow;
+    __syncthreads();
+    // ego disc centres per kept pose and their bounding box
+    double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
+    for (int f = lane; f < na; f += WAVE) {
+        const int i = s_keep[f];
+        const double px = rem[3 * i], py = rem[3 * i + 1], c = rcs[2 * i], s = rcs[2 * i + 1];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
+            const double ex = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
+            const double ey = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
+            s_ego[f][2 * d] = ex; s_ego[f][2 * d + 1] = ey;
+            bx0 = fmin(bx0, ex); bx1 = fmax(bx1, ex); by0 = fmin(by0, ey); by1 = fmax(by1, ey);
+        }
+    }
+    bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
+    const double slack = md * (1.0 + 1e-9) + 1e-9;      // conservative: never culls a pair within md
+    bx0 -= slack; by0 -= slack; bx1 += slack; by1 += slack;
+    __syncthreads();
+
+    // ---- cull obstacle disc positions against the box; keep ids in reference order-independent form
+    const int ooff = a.obs_off[p], ocnt = a.obs_cnt[p], oskip = a.obs_skip ? a.obs_skip[p] : -1;
+    const int ncand_all = nobs * steps * 2;
+    int cbase = 0;
+    for (int c0 = 0; c0 < ncand_all; c0 += WAVE) {
+        const int cidx = c0 + lane;
+        bool keep = false;
+        if (cidx < ncand_all) {
+            const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;   // o: local obstacle rank
+            int pool = ooff + o;
+            if (oskip >= 0 && pool >= oskip) pool += 1;                                    // skip self
+            const double *q = a.pred + ((size_t)pool * steps + g) * 4 + 2 * co;
+            keep = (q[0] >= bx0) && (q[0] <= bx1) && (q[1] >= by0) && (q[1] <= by1);
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = cbase + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) s_cand[pos] = cidx;
+        cbase += __popcll(m);
+    }
+    (void)ocnt;
+    const int ncand = cbase;
+    __syncthreads();
+
+    // ---- exact test of survivors; key = reference row order (frame, agent disc, obstacle, offset, obstacle disc)
+    const int F = na > steps ? na : steps;
+    const long long NOKEY = 0x7fffffffffffffffLL;
+    long long best = NOKEY;
+    const long long npairs = (long long)ncand * F;
+    for (long long q0 = 0; q0 < npairs; q0 += WAVE) {
+        const long long qi = q0 + lane;
+        if (qi < npairs) {
+            const int ci = (int)(qi / F), f = (int)(qi % F);
+            const int cidx = s_cand[ci];
+            const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;
+            const int ff = f < steps ? f : steps - 1;
+            if (abs(g - ff) <= w) {      // some offset d in [-w, w] maps padded frame ff onto obstacle frame g
+                int pool = ooff + o;
+                if (oskip >= 0 && pool >= oskip) pool += 1;
+                const double *qq = a.pred + ((size_t)pool * steps + g) * 4 + 2 * co;
+                const double ox = qq[0], oy = qq[1];
+                const int fe = f < na ? f : na - 1;
+#pragma unroll
+                for (int ca = 0; ca < 2; ca++) {
+                    if (dist2d(s_ego[fe][2 * ca], s_ego[fe][2 * ca + 1], ox, oy) <= md) {
+                        // offsets ascend => obstacle frames descend; first offset reaching g is the one that counts
+                        const long long key = ((((long long)f * 2 + ca) * MPCX_MAX_OBS + o) * MPCX_PRED_STEPS_MAX + (steps - 1 - g)) * 2 + co;
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        }
+    }
+    best = wave_min_ll(best);
+    if (best == NOKEY) {
+        if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        return;
+    }
+    // decode the obstacle disc of the first row
+    const int co = (int)(best & 1);
+    const int g = steps - 1 - (int)((best >> 1) % MPCX_PRED_STEPS_MAX);
+    const int o = (int)(((best >> 1) / MPCX_PRED_STEPS_MAX) % MPCX_MAX_OBS);
+    int pool = ooff + o;
+    if (oskip >= 0 && pool >= oskip) pool += 1;
+    const double ox = a.pred[((size_t)pool * steps + g) * 4 + 2 * co], oy = a.pred[((size_t)pool * steps + g) * 4 + 2 * co + 1];
+
+    // ---- collision_avoidance.py:88-104: earliest pose of the detailed path (front-disc block, then rear-disc block)
+    int first = 0x7fffffff;
+    for (int i = lane; i < n; i += WAVE) {
+        const double px = rem[3 * i], py = rem[3 * i + 1], c = rcs[2 * i], s = rcs[2 * i + 1];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
+            const double ex = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
+            const double ey = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
+            if (dist2d(ox, oy, ex, ey) <= md) { const int key = d * n + i; first = key < first ? key : first; }
+        }
+    }
+    first = wave_min_i(first);
+    first = (first == 0x7fffffff) ? 0 : first % n;      // argmax of an all-False mask is 0
+    const double hx = rem[3 * first], hy = rem[3 * first + 1];
+
+    // ---- collision_avoidance.py:107-119 on trajectory_full, then mpc_intersection.py:130-134
+    int cut = 0x7fffffff;
+    for (int j = lane; j < len; j += WAVE)
+        if (dist2d(path[3 * j], path[3 * j + 1], hx, hy) <= 0.001) cut = j < cut ? j : cut;
+    cut = wave_min_i(cut);
+    int cl = len;
+    if (cut != 0x7fffffff) { cl = cut - ip.cutoff_margin; cl = cl > tidx + 1 ? cl : tidx + 1; }
+    if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = hx; a.hit_xy[2 * p + 1] = hy; a.cut_len[p] = cl; }
+}
+
+}  // namespace mpcx
+
+extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip, int32_t P,
+                                          const double *state, const double *path_xyyaw, const double *path_cs,
+                                          const int32_t *path_off, const int32_t *path_len, const int32_t *prev_cut_len,
+                                          int32_t n_obs_pool, const double *obs6, const int32_t *obs_off,
+                                          const int32_t *obs_cnt, const int32_t *obs_skip,
+                                          int32_t *traj_idx, int32_t *hit_idx, double *hit_xy, int32_t *cut_len) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (!ip || P < 0 || n_obs_pool < 0 || !state || !path_xyyaw || !path_cs || !path_off || !path_len || !obs_off ||
+        !obs_cnt || !traj_idx || !hit_idx || !hit_xy || !cut_len || (n_obs_pool > 0 && !obs6))
+        return mpcx_fail(ctx, MPCX_E_INVALID, "interaction_batch: null pointer or negative size");
+    if (ip->pred_steps < 1 || ip->pred_steps > MPCX_PRED_STEPS_MAX || ip->frame_window < 0 || !(ip->dt > 0) || !(ip->L > 0))
+        return mpcx_fail(ctx, MPCX_E_INVALID, "interaction_batch: pred_steps outside 1..%d or bad dt/L/frame_window", MPCX_PRED_STEPS_MAX);
+    if (P == 0) return MPCX_OK;
+    const size_t need = (size_t)(n_obs_pool > 0 ? n_obs_pool : 1) * ip->pred_steps * 4;
+    if (need > ctx->pred_cap) {
+        if (ctx->pred) (void)hipFree(ctx->pred);
+        ctx->pred = nullptr; ctx->pred_cap = 0;
+        if (hipMalloc((void **)&ctx->pred, need * sizeof(double)) != hipSuccess)
+            return mpcx_fail(ctx, MPCX_E_LAUNCH, "interaction_batch: cannot allocate %zu bytes of prediction scratch", need * sizeof(double));
+        ctx->pred_cap = need;
+    }
+    if (n_obs_pool > 0) {
+        mpcx::PredArgs pa{*ip, n_obs_pool, obs6, ctx->pred};
+        hipLaunchKernelGGL(mpcx::predict_kernel, dim3((n_obs_pool + 255) / 256), dim3(256), 0, ctx->stream, pa);
+    }
+    mpcx::InterArgs ia{*ip, P, state, path_xyyaw, path_cs, path_off, path_len, prev_cut_len, ctx->pred,
+                       obs_off, obs_cnt, obs_skip, traj_idx, hit_idx, hit_xy, cut_len};
+    hipLaunchKernelGGL(mpcx::interaction_kernel, dim3(P), dim3(64), 0, ctx->stream, ia);
+    return mpcx_check_launch(ctx, "interaction kernels");
+}

@@ -1,0 +1,142 @@
+// mpcx_prepare.hip -- reference window, warm-start rollout and plant update, batched.
+//
+// Replaces (paths relative to /root/reference/main):
+//   lib/mpc.py:86-109   _calc_ref_trajectory      -> ref_window_kernel  (one wavefront per instance)
+//   lib/trajectories.py:100-126 calc_nearest_index_in_direction (inside the above)
+//   lib/mpc.py:112-126  _predict_motion            -> rollout_kernel     (one thread per instance)
+//   lib/simulation.py:35-47 Simulation.step + bicycle/main.py:28-41      -> plant_kernel / rollout
+// Arithmetic follows the reference's operation order; products are kept un-fused (-ffp-contract is
+// irrelevant here because every product/sum below goes through __dmul_rn/__dadd_rn where order matters).
+#include "mpcx_common.h"
+
+namespace mpcx {
+
+struct RefArgs {
+    mpcx_mpc_params p;
+    int B;
+    const double *state, *path;
+    const int32_t *path_off, *path_len;
+    double dl;
+    int32_t *target_ind;
+    double *xref;
+    uint8_t *re;
+};
+
+__global__ __launch_bounds__(64) void ref_window_kernel(RefArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int T = a.p.T, W = T + 1;
+    const double *path = a.path + 3 * (size_t)a.path_off[b];
+    const int n = a.path_len[b];
+    const double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2];
+    int start = a.target_ind[b];
+    int s = (start < 0 || n <= 0) ? -1 : nearest_index_in_direction(path, n, start, x, y, lane);
+    if (lane == 0) a.target_ind[b] = s;
+    double *xr = a.xref + (size_t)b * 4 * W;
+    uint8_t *re = a.re + (size_t)b * W;
+    if (s < 0) {  // reference raised: leave a defined (zero) window, caller sees target_ind = -1
+        if (lane <= T) { xr[lane] = 0; xr[W + lane] = 0; xr[2 * W + lane] = 0; xr[3 * W + lane] = 0; re[lane] = 0; }
+        return;
+    }
+    // mpc.py:95-100: ov = max(v, 10/3.6); travel = cumsum(|ov|*dt); idx = min(rint(travel/dl) + s, n-1)
+    const double ov = v > 10.0 / 3.6 ? v : 10.0 / 3.6;
+    const double step = __dmul_rn(fabs(ov), a.p.dt);
+    if (lane <= T) {
+        double travel = step;                       // np.cumsum: sequential adds
+        for (int k = 1; k <= lane; k++) travel = __dadd_rn(travel, step);
+        long long idx = (long long)rint(__ddiv_rn(travel, a.dl)) + s;
+        if (idx > n - 1) idx = n - 1;
+        xr[0 * W + lane] = path[3 * idx];
+        xr[1 * W + lane] = path[3 * idx + 1];
+        xr[2 * W + lane] = 0.0;
+        xr[3 * W + lane] = path[3 * idx + 2];
+        re[lane] = (idx == n - 1);
+    }
+}
+
+// simulation.py:35-47 + bicycle/main.py:28-41
+__device__ __forceinline__ void plant_step(const mpcx_mpc_params &p, double &x, double &y, double &v, double &th,
+                                           double a, double delta) {
+    delta = fmax(fmin(delta, p.max_steer), -p.max_steer);
+    double s, c;
+    sincos(th, &s, &c);
+    const double xd = __dmul_rn(v, c), yd = __dmul_rn(v, s), td = __dmul_rn(__ddiv_rn(v, p.L), tan(delta));
+    x = __dadd_rn(x, __dmul_rn(xd, p.dt));
+    y = __dadd_rn(y, __dmul_rn(yd, p.dt));
+    th = __dadd_rn(th, __dmul_rn(td, p.dt));
+    v = __dadd_rn(v, __dmul_rn(a, p.dt));
+    v = fmax(fmin(v, p.max_speed), p.min_speed);
+}
+
+struct RollArgs {
+    mpcx_mpc_params p;
+    int B;
+    const double *state, *u_warm;
+    double *xbar;
+};
+
+__global__ __launch_bounds__(256) void rollout_kernel(RollArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int T = a.p.T, W = T + 1;
+    double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2], th = a.state[4 * b + 3];
+    double *xb = a.xbar + (size_t)b * 4 * W;
+    xb[0] = x; xb[W] = y; xb[2 * W] = v; xb[3 * W] = th;
+    const double *oa = a.u_warm ? a.u_warm + (size_t)b * 2 * T : nullptr;
+    for (int t = 1; t <= T; t++) {
+        const double ai = oa ? oa[t - 1] : 0.0, di = oa ? oa[T + t - 1] : 0.0;   // mpc.py:222-224: zeros when no warm start
+        plant_step(a.p, x, y, v, th, ai, di);
+        xb[t] = x; xb[W + t] = y; xb[2 * W + t] = v; xb[3 * W + t] = th;
+    }
+}
+
+struct PlantArgs {
+    mpcx_mpc_params p;
+    int B;
+    double *state;
+    const double *u;
+    const int32_t *status;
+    double *applied;
+};
+
+// MPC.step's tail (mpc.py:294-297) + Simulation.step
+__global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int T = a.p.T;
+    double di = a.applied[2 * b], ai;
+    const bool ok = !a.status || a.status[b] == MPCX_QP_OPTIMAL;
+    if (ok) { di = a.u[(size_t)b * 2 * T + T]; ai = a.u[(size_t)b * 2 * T]; }
+    else ai = a.p.max_decel;
+    a.applied[2 * b] = di; a.applied[2 * b + 1] = ai;
+    double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2], th = a.state[4 * b + 3];
+    plant_step(a.p, x, y, v, th, ai, di);
+    a.state[4 * b] = x; a.state[4 * b + 1] = y; a.state[4 * b + 2] = v; a.state[4 * b + 3] = th;
+}
+
+}  // namespace mpcx
+
+extern "C" int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double *state, const double *u_warm,
+                                          const double *path_xyyaw, const int32_t *path_off, const int32_t *path_len,
+                                          double dl, int32_t *target_ind, double *xref, uint8_t *reaches_end, double *xbar) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");
+    if (B < 0 || !state || !path_xyyaw || !path_off || !path_len || !target_ind || !xref || !reaches_end || !xbar || !(dl > 0))
+        return mpcx_fail(ctx, MPCX_E_INVALID, "mpc_prepare_batch: null pointer, negative batch or dl <= 0");
+    if (B == 0) return MPCX_OK;
+    mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_off, path_len, dl, target_ind, xref, reaches_end};
+    hipLaunchKernelGGL(mpcx::ref_window_kernel, dim3(B), dim3(64), 0, ctx->stream, ra);
+    mpcx::RollArgs ro{ctx->mpc, B, state, u_warm, xbar};
+    hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, ro);
+    return mpcx_check_launch(ctx, "prepare kernels");
+}
+
+extern "C" int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state, const double *u,
+                                         const int32_t *status, double *applied) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");
+    if (B < 0 || !state || !u || !applied) return mpcx_fail(ctx, MPCX_E_INVALID, "plant_step_batch: null pointer");
+    if (B == 0) return MPCX_OK;
+    mpcx::PlantArgs pa{ctx->mpc, B, state, u, status, applied};
+    hipLaunchKernelGGL(mpcx::plant_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, pa);
+    return mpcx_check_launch(ctx, "plant_kernel");
+}

@@ -1,0 +1,423 @@
+// mpcx_qp.hip -- batched linear-time-varying MPC quadratic program, one wavefront per instance.
+//
+// Replaces lib/mpc.py:138-208 `_linear_mpc_control` (cvxpy problem build + ECOS solve) together with
+// lib/mpc.py:58-79 `_get_linear_model_matrix` and :129-135 `_get_xy_cost_mtx_for_orientation`
+// (paths relative to /root/reference/main).  See DESIGN.md "QP kernel" for the derivation.
+//
+// Formulation.  delta_bar = 0 always (mpc.py:93), so v_t and yaw_t are exact cumulative sums of the inputs
+// and only x,y couple accel and steer.  The states are eliminated (condensed QP in u = [a_0..a_{T-1},
+// d_0..d_{T-1}], n = 2T <= 64 unknowns): lane i of the wavefront owns unknown i, row i of the Hessian and
+// the four inequality rows attached to that unknown (a-lane k: a_k <= amax, -a_k <= -amin, +-v_{k+1} speed
+// rows; d-lane k: +-d_k box, +-(d_{k+1}-d_k) rate rows).  Sensitivities have closed forms in prefix sums of
+// the linearisation coefficients, the constraint matrix is never formed: G'DG is "diag + dt^2*min(S_i,S_k)"
+// on the accel block (S = suffix sums of the speed-row weights) and tridiagonal on the steer block.
+// Solver: Mehrotra predictor-corrector primal-dual interior point; per iteration one register-resident
+// right-looking Cholesky (row i in lane i's VGPRs, column broadcast through a double-buffered LDS line,
+// lane j keeps its (unscaled) Schur row as the transposed factor row, so both triangular sweeps run from
+// registers) and two solves whose pivots travel by v_readlane.
+#include "mpcx_common.h"
+
+namespace mpcx {
+
+struct QpArgs {
+    mpcx_mpc_params p;
+    int B;
+    const double *x0, *xref, *xbar, *u_warm;
+    const uint8_t *re;
+    double *x_out, *u_out, *kkt;
+    int32_t *status, *iters;
+};
+
+template <int NT>
+struct QpShared {
+    static constexpr int N = 2 * NT;
+    double H[N * N];        // column-major: H[k*N + i] = H(i,k); lane i reads/writes its own row conflict-free
+    double pre[6][NT + 1];  // exclusive prefix sums over t: Px, Py (accel paths), Qx, Qy (steer paths), Cx, Cy (affine)
+    double beta[32];        // dt * vbar_k / L
+    double wt[33][6];       // per-t cost weights: wxx, wxy, wyy, wv, wyaw
+    double we[NT + 1][4];   // W_t * (free response - reference)
+    double gb[WAVE][4];     // W_t * sensitivity of every unknown at the current t (Hessian build broadcast)
+    double cb[2][WAVE];     // Cholesky column broadcast (double buffered)
+    double ub[WAVE];        // current iterate broadcast
+    double sb[WAVE];        // speed-row suffix sums broadcast
+};
+
+// All hot loops below are written branch-free (selects / 0-1 masks): a single straight-line block keeps the
+// register allocator out of scratch.  The block is ONE wavefront, so LDS traffic between lanes is ordered by
+// the in-order LDS queue; `lds_sync()` only stops the compiler from reordering across it.
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_sched_barrier(0);      // keep the (huge, fully unrolled) blocks from being reordered wholesale
+}
+
+// Optimisation barrier: the value must exist in a VGPR here.  Without it LLVM sinks the ~10^3 accumulator
+// updates of the unrolled loops below their last use and spills every operand to scratch.
+__device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
+
+// forward/backward substitution with the factor held as: lane i, R[k] = L(i,k) for k<i, 0 for k==i and, for
+// k>i, the UNSCALED Schur-complement entry M_i(i,k) = L(k,i)*L(i,i) the lane held when its column was
+// eliminated; invd = 1/L(i,i).  (Scaling that transposed part in place would need a per-element select or
+// lose sqrt(pivot) digits to cancellation; the backward sweep applies invd once per lane instead.)
+template <int N>
+__device__ __forceinline__ double chol_solve(const double (&R)[N], double invd, double b, int lane) {
+    double acc = b, y = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double tmp = acc * invd;
+        double yj = rdlane(tmp, j);
+        y = (lane == j) ? tmp : y;
+        acc = fma(-R[j], yj, acc);
+    }
+    double sum = 0.0, x = 0.0;
+#pragma unroll
+    for (int j = N - 1; j >= 0; j--) {
+        double tmp = fma(-invd, sum, y) * invd;
+        double xj = rdlane(tmp, j);
+        x = (lane == j) ? tmp : x;
+        sum = fma(R[j], xj, sum);
+    }
+    return x;
+}
+
+template <int NT>
+__global__ __launch_bounds__(64, 2) void qp_kernel(QpArgs a) {
+    constexpr int N = 2 * NT;
+    __shared__ QpShared<NT> sh;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const mpcx_mpc_params &P = a.p;
+    const int T = P.T, W = T + 1;
+    const double dt = P.dt;
+
+    const double *xref = a.xref + (size_t)b * 4 * W;
+    const double *xbar = a.xbar + (size_t)b * 4 * W;
+    const uint8_t *re = a.re + (size_t)b * W;
+    const double x0 = a.x0[4 * b + 0], y0 = a.x0[4 * b + 1], v0 = a.x0[4 * b + 2], yaw0 = a.x0[4 * b + 3];
+
+    const int kind = lane >= NT;            // 0: accel unknown, 1: steer unknown
+    const int k = lane - kind * NT;         // stage of this unknown
+    const bool inrow = lane < N;
+    const bool real = inrow && (k < T);
+    const int kc = real ? k : 0;            // clamped stage for table reads
+    const int li = inrow ? lane : N - 1;    // clamped row for H reads
+
+    // ---------------------------------------------------------------- per-stage linearisation + weights
+    // lanes [0,32): dynamics at xbar[:,t]; lanes [32,64): cost rotation at xref[3,t']   (one sincos for both)
+    {
+        const bool dyn = lane < 32;
+        const int t = dyn ? lane : (lane - 32 + 1);      // dynamics stage 0..31 | cost stage 1..32
+        const bool on = dyn ? (t < T) : (t <= T);
+        const int tc = on ? t : 0;
+        const double vb = (dyn && on) ? xbar[2 * W + tc] : 0.0;
+        const double ang = on ? (dyn ? xbar[3 * W + tc] : xref[3 * W + tc]) : 0.0;
+        const bool ended = (!dyn && on) ? (re[tc] != 0) : false;
+        double s, c;
+        sincos(ang, &s, &c);
+        // mpc.py:58-79 with delta = 0:  A[0,2]=dt c, A[0,3]=-dt v s, A[1,2]=dt s, A[1,3]=dt v c,
+        //                               C[0]=dt v s phi, C[1]=-dt v c phi, B[3,1]=dt v / L
+        const double m = (dyn && on) ? 1.0 : 0.0;
+        double vals[6] = {m * (dt * c), m * (dt * s), m * (-dt * vb * s), m * (dt * vb * c),
+                          m * (dt * vb * s * ang), m * (-dt * vb * c * ang)};
+        if (dyn) sh.beta[t] = m * (dt * vb / P.L);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            double v = scan_up(vals[r], lane);           // lanes >= 32 contribute zeros
+            if (dyn && t < NT) sh.pre[r][t + 1] = v;
+            if (lane == 0) sh.pre[r][0] = 0.0;
+        }
+        if (!dyn) {
+            // mpc.py:160-170; cos(psi+pi/2) = -sin(psi), sin(psi+pi/2) = cos(psi)
+            double wxx = (s * s) * P.w_perp + (c * c) * P.w_para;
+            double wxy = (-s * c) * P.w_perp + (c * s) * P.w_para;
+            double wyy = (c * c) * P.w_perp + (s * s) * P.w_para;
+            double wv = P.Q_v_yaw[0], wp = P.Q_v_yaw[1];
+            if (ended) { wxx = P.Qf[0]; wxy = 0.0; wyy = P.Qf[1]; wv = P.Qf[2]; wp = P.Qf[3]; }
+            const double mm = on ? 1.0 : 0.0;
+            sh.wt[t][0] = mm * wxx; sh.wt[t][1] = mm * wxy; sh.wt[t][2] = mm * wyy; sh.wt[t][3] = mm * wv; sh.wt[t][4] = mm * wp;
+        }
+        if (lane == 0) { sh.wt[0][0] = 0; sh.wt[0][1] = 0; sh.wt[0][2] = 0; sh.wt[0][3] = 0; sh.wt[0][4] = 0; }
+    }
+    lds_sync();
+    // W_t (free response - reference): the free response has v = v0, yaw = yaw0 at every stage
+    if (lane <= NT) {
+        const int t = lane;
+        const bool on = (t >= 1 && t <= T);
+        const int tc = on ? t : 0;
+        const double xf = x0 + v0 * sh.pre[0][tc] + yaw0 * sh.pre[2][tc] + sh.pre[4][tc];
+        const double yf = y0 + v0 * sh.pre[1][tc] + yaw0 * sh.pre[3][tc] + sh.pre[5][tc];
+        const double e0 = xf - xref[0 * W + tc], e1 = yf - xref[1 * W + tc];
+        const double e2 = v0 - xref[2 * W + tc], e3 = yaw0 - xref[3 * W + tc];
+        sh.we[t][0] = sh.wt[t][0] * e0 + sh.wt[t][1] * e1;     // weights are zero when !on
+        sh.we[t][1] = sh.wt[t][1] * e0 + sh.wt[t][2] * e1;
+        sh.we[t][2] = sh.wt[t][3] * e2;
+        sh.we[t][3] = sh.wt[t][4] * e3;
+    }
+    lds_sync();
+
+    // ---------------------------------------------------------------- condensed Hessian row + gradient
+    double R[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) R[j] = 0.0;
+    double g = 0.0;
+    {
+        const double coef = real ? (kind ? sh.beta[kc] : dt) : 0.0;
+        const double *bxp = sh.pre[kind ? 2 : 0], *byp = sh.pre[kind ? 3 : 1];
+        const double bx0 = bxp[kc + 1], by0 = byp[kc + 1];
+        const double cv = kind ? 0.0 : coef, cp = kind ? coef : 0.0;
+#pragma unroll
+        for (int t = 1; t <= NT; t++) {
+            const double act = (real && (t >= k + 1)) ? 1.0 : 0.0;     // stages t > T carry zero weights
+            const double ca = act * coef;
+            const double gx = ca * (bxp[t] - bx0), gy = ca * (byp[t] - by0), gv = act * cv, gp = act * cp;
+            const double wxx = sh.wt[t][0], wxy = sh.wt[t][1], wyy = sh.wt[t][2], wv = sh.wt[t][3], wp = sh.wt[t][4];
+            sh.gb[lane][0] = wxx * gx + wxy * gy;
+            sh.gb[lane][1] = wxy * gx + wyy * gy;
+            sh.gb[lane][2] = wv * gv;
+            sh.gb[lane][3] = wp * gp;
+            g += gx * sh.we[t][0] + gy * sh.we[t][1] + gv * sh.we[t][2] + gp * sh.we[t][3];
+            lds_sync();
+            // only unknowns of stages < t have a non-zero sensitivity at time t
+#pragma unroll
+            for (int kk = 0; kk < t; kk++) {
+                R[kk] += gx * sh.gb[kk][0] + gy * sh.gb[kk][1] + gv * sh.gb[kk][2] + gp * sh.gb[kk][3];
+                R[NT + kk] += gx * sh.gb[NT + kk][0] + gy * sh.gb[NT + kk][1] + gv * sh.gb[NT + kk][2] + gp * sh.gb[NT + kk][3];
+                pin(R[kk]); pin(R[NT + kk]);
+            }
+            lds_sync();
+        }
+        g *= 2.0;
+        // input cost (mpc.py:177-180) and input-rate cost (mpc.py:182-183); objective has no 1/2 => H = 2*(...)
+        const double rr = re[kc] ? P.R_end[kind] : P.R[kind];
+        const double rdc = P.Rd[kind];
+        const int nb = (k >= 1) + (k + 1 < T);
+        const double dg = real ? (2.0 * rr + 2.0 * rdc * nb) : 1.0;     // padding unknowns: identity row
+        const double off_lo = (real && k >= 1) ? -2.0 * rdc : 0.0;
+        const double off_hi = (real && k + 1 < T) ? -2.0 * rdc : 0.0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            double v = 2.0 * R[j];
+            v += (lane == j) ? dg : 0.0;
+            v += (lane == j + 1) ? off_lo : 0.0;
+            v += (lane == j - 1) ? off_hi : 0.0;
+            R[j] = v;
+        }
+        if (inrow) {
+#pragma unroll
+            for (int j = 0; j < N; j++) sh.H[j * N + lane] = R[j];
+        }
+    }
+
+    // ---------------------------------------------------------------- constraints owned by this lane
+    // rows 0/1: +-u_i box ; rows 2/3: accel lane k -> +-v_{k+1} speed rows, steer lane k -> +-(d_{k+1}-d_k)
+    const bool val01 = real;
+    const bool val23 = real && (kind == 0 || k + 1 < T);
+    const double h0 = kind ? P.max_steer : P.max_accel;
+    const double h1 = kind ? P.max_steer : -P.max_decel;
+    const double h2 = kind ? P.max_dsteer * dt : P.max_speed - v0;
+    const double h3 = kind ? P.max_dsteer * dt : v0 - P.min_speed;
+    const double m01 = val01 ? 1.0 : 0.0, m23 = val23 ? 1.0 : 0.0;
+    const double minv = 1.0 / (double)(8 * T - 2);
+    const double ma = (kind == 0 && real) ? 1.0 : 0.0;     // accel lane mask
+    const double k0m = (k == 0) ? 0.0 : 1.0;
+
+    double u = 0.0;
+    if (real && a.u_warm) u = a.u_warm[(size_t)b * 2 * T + kind * T + k];
+
+    // (G x) of the second row pair: accel lane: dt * sum_{j<=k} a_j ; steer lane: d_{k+1} - d_k
+    auto second_rows = [&](double x) -> double {
+        const double pa = scan_up(ma * x, lane);
+        const double nx = __shfl_down(x, 1, WAVE);
+        return m23 * (kind == 0 ? dt * pa : (nx - x));
+    };
+    // (G' w) for this unknown from the lane's w0..w3 (already masked)
+    auto gt_apply = [&](double w0, double w1, double w2, double w3) -> double {
+        const double q = w2 - w3;
+        const double sa = scan_down(ma * q, lane);             // sum_{j>=k} q_j over accel lanes
+        const double qp = k0m * __shfl_up(q, 1, WAVE);         // q_{k-1}
+        return (w0 - w1) + (kind == 0 ? dt * sa : (qp - q));
+    };
+
+    double s0, s1, s2, s3, l0 = 1.0, l1 = 1.0, l2 = 1.0, l3 = 1.0;
+    {
+        const double e2 = second_rows(u);
+        s0 = fmax(h0 - u, 0.5); s1 = fmax(h1 + u, 0.5); s2 = fmax(h2 - e2, 0.5); s3 = fmax(h3 + e2, 0.5);
+    }
+    const double gnorm = fmax(1.0, wave_max(real ? fabs(g) : 0.0));
+    const double hnorm = fmax(1.0, wave_max(fmax(m01 * fmax(fabs(h0), fabs(h1)), m23 * fmax(fabs(h2), fabs(h3)))));
+
+    int status = MPCX_QP_MAXITER;
+    int it = 0;
+    double res_d = 0, res_p = 0, mu = 0;
+    const double dt2 = dt * dt;
+    // x[2,0] rows of mpc.py:187-188 are constants: outside the speed interval the problem is infeasible
+    const bool feasible0 = !(v0 > P.max_speed + 1e-9 || v0 < P.min_speed - 1e-9);
+    if (!feasible0) status = MPCX_QP_INFEASIBLE;
+    const int max_iter = feasible0 ? P.max_iter : -1;
+
+    for (it = 0; it <= max_iter; it++) {
+        // -------- residuals
+        sh.ub[lane] = u;
+        lds_sync();
+        double hu = 0.0;
+        const double rowm = inrow ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            R[j] = rowm * sh.H[j * N + li];
+            hu = fma(R[j], sh.ub[j], hu);
+        }
+        const double e2 = second_rows(u);
+        const double rd = m01 * (hu + g + gt_apply(m01 * l0, m01 * l1, m23 * l2, m23 * l3));
+        const double rp0 = m01 * (u + s0 - h0), rp1 = m01 * (-u + s1 - h1);
+        const double rp2 = m23 * (e2 + s2 - h2), rp3 = m23 * (-e2 + s3 - h3);
+        mu = wave_sum(m01 * (s0 * l0 + s1 * l1) + m23 * (s2 * l2 + s3 * l3)) * minv;
+        res_d = wave_max(fabs(rd));
+        res_p = wave_max(fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))));
+#ifdef MPCX_QP_TRACE
+        if (b == MPCX_QP_TRACE && lane == 0) printf("it %d res_d %.3e res_p %.3e mu %.3e gnorm %.3e hnorm %.3e\n", it, res_d, res_p, mu, gnorm, hnorm);
+#endif
+        if (res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol) { status = MPCX_QP_OPTIMAL; break; }
+        if (it == max_iter) break;
+
+        // -------- M = H + G' D G  (row `lane` in R[])
+        const double is0 = frcp(s0), is1 = frcp(s1), is2 = frcp(s2), is3 = frcp(s3);
+        const double d0 = m01 * l0 * is0, d1 = m01 * l1 * is1, d2 = m23 * l2 * is2, d3 = m23 * l3 * is3;
+        const double r23 = d2 + d3;
+        const double S = scan_down(ma * r23, lane);      // accel lanes: sum_{j>=k} (d2+d3)_j ; elsewhere 0
+        sh.sb[lane] = S;
+        lds_sync();
+        const double r_own = kind ? r23 : 0.0;
+        const double r_prev = k0m * __shfl_up(r_own, 1, WAVE);
+        const double dgm = d0 + d1 + r_own + r_prev;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (j < NT) R[j] = fma(dt2, fmin(S, sh.sb[j]), R[j]);
+            double add = (lane == j) ? dgm : 0.0;
+            add = (lane == j - 1) ? -r_own : add;
+            add = (lane == j + 1) ? -r_prev : add;
+            R[j] += add;
+        }
+
+        // -------- Cholesky (right-looking; see file header)
+        double invd = 1.0;
+        bool bad = false;
+        sh.cb[0][lane] = R[0];
+        lds_sync();
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const double *col = sh.cb[j & 1];
+            double d = col[j];
+            bad = bad || !(d > 0.0);
+            d = (d > 0.0) ? d : 1.0;
+            const double rinv = frcp(d), rs = frsq(d);
+            const double tj = (lane > j) ? R[j] * rinv : 0.0;
+            if (j + 1 < N) {
+                R[j + 1] = fma(-tj, col[j + 1], R[j + 1]);
+                sh.cb[(j + 1) & 1][lane] = R[j + 1];
+            }
+#pragma unroll
+            for (int kk = j + 2; kk < N; kk++) { R[kk] = fma(-tj, col[kk], R[kk]); pin(R[kk]); }
+            R[j] = (lane > j) ? R[j] * rs : ((lane == j) ? 0.0 : R[j]);
+            invd = (lane == j) ? rs : invd;
+            lds_sync();
+        }
+        if (bad) { status = MPCX_QP_NUMERIC; break; }
+
+        // -------- predictor (affine scaling) direction
+        double w0 = -m01 * l0 + d0 * rp0, w1 = -m01 * l1 + d1 * rp1, w2 = -m23 * l2 + d2 * rp2, w3 = -m23 * l3 + d3 * rp3;
+        double rhs = m01 * (-rd - gt_apply(w0, w1, w2, w3));
+        double du = m01 * chol_solve<N>(R, invd, rhs, lane);
+        double f2 = second_rows(du);
+        const double dsa0 = -rp0 - m01 * du, dsa1 = -rp1 + m01 * du, dsa2 = -rp2 - f2, dsa3 = -rp3 + f2;
+        const double dla0 = m01 * (-l0 - d0 * dsa0), dla1 = m01 * (-l1 - d1 * dsa1);
+        const double dla2 = m23 * (-l2 - d2 * dsa2), dla3 = m23 * (-l3 - d3 * dsa3);
+        const double il0 = frcp(l0), il1 = frcp(l1), il2 = frcp(l2), il3 = frcp(l3);
+        // largest step keeping s, lam >= 0: 1 / max(-ds/s, -dlam/lam)
+        double rat = fmax(fmax(-dsa0 * is0, -dla0 * il0), fmax(-dsa1 * is1, -dla1 * il1));
+        rat = fmax(rat, fmax(fmax(-dsa2 * is2, -dla2 * il2), fmax(-dsa3 * is3, -dla3 * il3)));
+        rat = wave_max(rat);
+        const double al = (rat > 1.0) ? frcp(rat) : 1.0;
+        double mu_aff = m01 * ((s0 + al * dsa0) * (l0 + al * dla0) + (s1 + al * dsa1) * (l1 + al * dla1)) +
+                        m23 * ((s2 + al * dsa2) * (l2 + al * dla2) + (s3 + al * dsa3) * (l3 + al * dla3));
+        mu_aff = wave_sum(mu_aff) * minv;
+        double sigma = mu_aff * frcp(mu);
+        sigma = sigma * sigma * sigma;
+        const double smu = sigma * mu;
+
+        // -------- corrector
+        const double rc0 = s0 * l0 + dsa0 * dla0 - smu, rc1 = s1 * l1 + dsa1 * dla1 - smu;
+        const double rc2 = s2 * l2 + dsa2 * dla2 - smu, rc3 = s3 * l3 + dsa3 * dla3 - smu;
+        w0 = m01 * (-rc0 + l0 * rp0) * is0; w1 = m01 * (-rc1 + l1 * rp1) * is1;
+        w2 = m23 * (-rc2 + l2 * rp2) * is2; w3 = m23 * (-rc3 + l3 * rp3) * is3;
+        rhs = m01 * (-rd - gt_apply(w0, w1, w2, w3));
+        du = m01 * chol_solve<N>(R, invd, rhs, lane);
+        f2 = second_rows(du);
+        const double ds0 = -rp0 - m01 * du, ds1 = -rp1 + m01 * du, ds2 = -rp2 - f2, ds3 = -rp3 + f2;
+        const double dl0 = -m01 * (rc0 + l0 * ds0) * is0, dl1 = -m01 * (rc1 + l1 * ds1) * is1;
+        const double dl2 = -m23 * (rc2 + l2 * ds2) * is2, dl3 = -m23 * (rc3 + l3 * ds3) * is3;
+        rat = fmax(fmax(-ds0 * is0, -dl0 * il0), fmax(-ds1 * is1, -dl1 * il1));
+        rat = fmax(rat, fmax(fmax(-ds2 * is2, -dl2 * il2), fmax(-ds3 * is3, -dl3 * il3)));
+        rat = wave_max(rat);
+        const double alpha = (0.995 < rat) ? 0.995 * frcp(rat) : 1.0;     // min(1, 0.995/rat)
+        u += alpha * du;
+        s0 += alpha * ds0; s1 += alpha * ds1; s2 += alpha * ds2; s3 += alpha * ds3;
+        l0 += alpha * dl0; l1 += alpha * dl1; l2 += alpha * dl2; l3 += alpha * dl3;
+    }
+
+    // ---------------------------------------------------------------- outputs: u and the linear prediction x
+    if (real) a.u_out[(size_t)b * 2 * T + kind * T + k] = u;
+    sh.ub[lane] = u;
+    lds_sync();
+    {
+        const int s = lane;                       // stage s -> state at s+1
+        const bool on = s < T;
+        const int sc = on ? s : 0;
+        const double onm = on ? 1.0 : 0.0;
+        const double as = onm * sh.ub[sc], dsb = onm * sh.ub[NT + sc] * sh.beta[sc];
+        const double va = scan_up(as, lane), fd = scan_up(dsb, lane);
+        const double vs = dt * (va - as), ps = fd - dsb;       // deviation of (v, yaw) at stage s from (v0, yaw0)
+        const double p0 = sh.pre[0][sc + 1] - sh.pre[0][sc], p1 = sh.pre[1][sc + 1] - sh.pre[1][sc];
+        const double q0 = sh.pre[2][sc + 1] - sh.pre[2][sc], q1 = sh.pre[3][sc + 1] - sh.pre[3][sc];
+        const double ix = onm * (p0 * vs + q0 * ps), iy = onm * (p1 * vs + q1 * ps);
+        const double X = scan_up(ix, lane), Y = scan_up(iy, lane);
+        double *xo = a.x_out + (size_t)b * 4 * W;
+        if (on) {
+            const int t = s + 1;
+            xo[0 * W + t] = x0 + v0 * sh.pre[0][t] + yaw0 * sh.pre[2][t] + sh.pre[4][t] + X;
+            xo[1 * W + t] = y0 + v0 * sh.pre[1][t] + yaw0 * sh.pre[3][t] + sh.pre[5][t] + Y;
+            xo[2 * W + t] = v0 + dt * va;
+            xo[3 * W + t] = yaw0 + fd;
+        }
+        if (lane == 0) { xo[0] = x0; xo[W] = y0; xo[2 * W] = v0; xo[3 * W] = yaw0; }
+    }
+    if (lane == 0) {
+        a.status[b] = status;
+        a.iters[b] = it;
+        a.kkt[4 * b + 0] = res_d; a.kkt[4 * b + 1] = res_p; a.kkt[4 * b + 2] = mu; a.kkt[4 * b + 3] = 0.0;
+    }
+}
+
+template <int NT>
+static void launch_qp(const QpArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(qp_kernel<NT>, dim3(a.B), dim3(64), 0, st, a);
+}
+
+}  // namespace mpcx
+
+extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x0, const double *xref,
+                                       const double *xbar, const uint8_t *reaches_end, const double *u_warm,
+                                       double *x_out, double *u_out, int32_t *status, int32_t *iters, double *kkt) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");
+    if (B < 0 || !x0 || !xref || !xbar || !reaches_end || !x_out || !u_out || !status || !iters || !kkt)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: null pointer or negative batch");
+    if (B == 0) return MPCX_OK;
+    mpcx::QpArgs a{ctx->mpc, B, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters};
+    const int T = ctx->mpc.T;
+    if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream);
+    else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream);
+    else if (T <= 20) mpcx::launch_qp<20>(a, ctx->stream);
+    else mpcx::launch_qp<32>(a, ctx->stream);
+    return mpcx_check_launch(ctx, "qp_kernel");
+}

@@ -1,0 +1,248 @@
+"""Thin device runtime over the C ABI (include/mpcx.h): torch-ROCm tensors own the device buffers, every
+computation happens in libmpcx.so's HIP kernels.  No CPU fallback exists: constructing a Context without a
+GPU or without the built library raises."""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class MpcParams:
+    """main/config/mpc_config.json + lib/mpc.py:17-36 + lib/simulation.py:23-25 of the reference."""
+    T: int = 13
+    dt: float = 0.2
+    L: float = 2.86
+    w_perp: float = 20.0
+    w_para: float = 1.0
+    R: Sequence[float] = (0.01, 0.01)
+    Rd: Sequence[float] = (0.01, 1.0)
+    Q_v_yaw: Sequence[float] = (0.0, 0.5)
+    Qf_base: Sequence[float] = (1.0, 1.0, 0.0, 0.5)   # multiplied by T (mpc.py:25)
+    R_end: Sequence[float] = (10.0, 10.0)
+    max_speed: float = 30.0 / 3.6
+    min_speed: float = -5.0
+    max_accel: float = 2.0
+    max_decel: float = -10.0
+    max_steer: float = float(np.deg2rad(45.0))
+    max_dsteer: float = float(np.deg2rad(30.0))
+    max_iter: int = 60
+    tol: float = 1e-10
+
+    def to_c(self) -> _lib.MpcParamsC:
+        p = _lib.MpcParamsC()
+        p.T, p.max_iter, p.dt, p.L = int(self.T), int(self.max_iter), float(self.dt), float(self.L)
+        p.w_perp, p.w_para = float(self.w_perp), float(self.w_para)
+        p.R[:] = list(map(float, self.R)); p.Rd[:] = list(map(float, self.Rd))
+        p.Q_v_yaw[:] = list(map(float, self.Q_v_yaw))
+        p.Qf[:] = [float(q) * self.T for q in self.Qf_base]
+        p.R_end[:] = list(map(float, self.R_end))
+        p.max_speed, p.min_speed = float(self.max_speed), float(self.min_speed)
+        p.max_accel, p.max_decel = float(self.max_accel), float(self.max_decel)
+        p.max_steer, p.max_dsteer, p.tol = float(self.max_steer), float(self.max_dsteer), float(self.tol)
+        return p
+
+
+@dataclass
+class InteractionParams:
+    """scenario constants of main/scenarios/mpc_intersection.py:31,81-84 + car_dimensions.py"""
+    pred_steps: int = 35
+    frame_window: int = 20
+    cutoff_margin: int = 72
+    dt: float = 0.2
+    L: float = 2.86
+    radius: float = 2.0 / 2 ** 0.5
+    circle_centers: Sequence[float] = (2.18, 0.0, 0.68, 0.0)
+    max_accel: float = 2.0
+    max_speed: float = 30.0 / 3.6
+
+    def to_c(self) -> _lib.InteractionParamsC:
+        p = _lib.InteractionParamsC()
+        p.pred_steps, p.frame_window, p.cutoff_margin, p.reserved = int(self.pred_steps), int(self.frame_window), int(self.cutoff_margin), 0
+        p.dt, p.L, p.radius = float(self.dt), float(self.L), float(self.radius)
+        p.circle_centers[:] = list(map(float, self.circle_centers))
+        p.max_accel, p.max_speed = float(self.max_accel), float(self.max_speed)
+        return p
+
+
+class MpcxError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One mpcx_ctx bound to a torch device and (by default) torch's current stream on it."""
+
+    def __init__(self, device: int = 0, stream: Optional[torch.cuda.Stream] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise MpcxError('no GPU visible: the mpcx hot path is HIP-only (no CPU fallback)')
+        self.device = torch.device('cuda', device)
+        torch.cuda.set_device(self.device)
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._ctx = self.lib.mpcx_create(device, C.c_void_p(self.stream.cuda_stream))
+        if not self._ctx:
+            raise MpcxError('mpcx_create failed for device %d' % device)
+        self.params: Optional[MpcParams] = None
+
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self.lib.mpcx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MpcxError('mpcx error %d: %s' % (rc, self.lib.mpcx_last_error(self._ctx).decode()))
+
+    # ------------------------------------------------------------------ helpers
+    def f64(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    def i32(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+
+    def u8(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.uint8)).to(self.device)
+
+    def _want(self, t, dtype, shape=None, name='tensor'):
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
+            raise MpcxError('%s must be a contiguous %s tensor on %s' % (name, dtype, self.device))
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise MpcxError('%s has shape %s, expected %s' % (name, tuple(t.shape), tuple(shape)))
+        return t
+
+    # ------------------------------------------------------------------ entry points
+    def set_mpc_params(self, p: MpcParams):
+        cp = p.to_c()
+        self._chk(self.lib.mpcx_set_mpc_params(self._ctx, C.byref(cp)))
+        self.params = p
+
+    def qp_solve(self, x0, xref, xbar, reaches_end, u_warm=None, out=None):
+        """mpcx_qp_solve_batch. Returns dict(x (B,4,T+1), u (B,2,T), status, iters, kkt)."""
+        T = self.params.T
+        B = x0.shape[0]
+        f = torch.float64
+        self._want(x0, f, (B, 4), 'x0'); self._want(xref, f, (B, 4, T + 1), 'xref')
+        self._want(xbar, f, (B, 4, T + 1), 'xbar'); self._want(reaches_end, torch.uint8, (B, T + 1), 'reaches_end')
+        if u_warm is not None:
+            self._want(u_warm, f, (B, 2, T), 'u_warm')
+        if out is None:
+            out = dict(x=torch.empty((B, 4, T + 1), dtype=f, device=self.device),
+                       u=torch.empty((B, 2, T), dtype=f, device=self.device),
+                       status=torch.empty(B, dtype=torch.int32, device=self.device),
+                       iters=torch.empty(B, dtype=torch.int32, device=self.device),
+                       kkt=torch.empty((B, 4), dtype=f, device=self.device))
+        self._chk(self.lib.mpcx_qp_solve_batch(self._ctx, B, _ptr(x0), _ptr(xref), _ptr(xbar), _ptr(reaches_end),
+                                               _ptr(u_warm), _ptr(out['x']), _ptr(out['u']), _ptr(out['status']),
+                                               _ptr(out['iters']), _ptr(out['kkt'])))
+        return out
+
+    def prepare(self, state, u_warm, path, path_off, path_len, dl, target_ind, out=None):
+        """mpcx_mpc_prepare_batch. target_ind is updated in place. Returns dict(xref, reaches_end, xbar)."""
+        T = self.params.T
+        B = state.shape[0]
+        f = torch.float64
+        self._want(state, f, (B, 4), 'state'); self._want(path, f, None, 'path')
+        self._want(path_off, torch.int32, (B,), 'path_off'); self._want(path_len, torch.int32, (B,), 'path_len')
+        self._want(target_ind, torch.int32, (B,), 'target_ind')
+        if u_warm is not None:
+            self._want(u_warm, f, (B, 2, T), 'u_warm')
+        if out is None:
+            out = dict(xref=torch.empty((B, 4, T + 1), dtype=f, device=self.device),
+                       reaches_end=torch.empty((B, T + 1), dtype=torch.uint8, device=self.device),
+                       xbar=torch.empty((B, 4, T + 1), dtype=f, device=self.device))
+        self._chk(self.lib.mpcx_mpc_prepare_batch(self._ctx, B, _ptr(state), _ptr(u_warm), _ptr(path), _ptr(path_off),
+                                                  _ptr(path_len), C.c_double(float(dl)), _ptr(target_ind),
+                                                  _ptr(out['xref']), _ptr(out['reaches_end']), _ptr(out['xbar'])))
+        return out
+
+    def plant_step(self, state, u, status, applied):
+        B = state.shape[0]
+        self._want(state, torch.float64, (B, 4), 'state'); self._want(applied, torch.float64, (B, 2), 'applied')
+        self._chk(self.lib.mpcx_plant_step_batch(self._ctx, B, _ptr(state), _ptr(u), _ptr(status), _ptr(applied)))
+
+    def search_model(self, templates, last_pose, edge_cost, hp, hp_off):
+        return SearchModel(self, templates, last_pose, edge_cost, hp, hp_off)
+
+    def expand(self, model: 'SearchModel', nodes, out=None):
+        """mpcx_expand_batch: nodes (n,3) -> dict(nbr (n,P,3), cost (n,P), collide (n,P) uint8)."""
+        n = nodes.shape[0]
+        self._want(nodes, torch.float64, (n, 3), 'nodes')
+        Pn = model.n_prim
+        if out is None:
+            out = dict(nbr=torch.empty((n, Pn, 3), dtype=torch.float64, device=self.device),
+                       cost=torch.empty((n, Pn), dtype=torch.float64, device=self.device),
+                       collide=torch.empty((n, Pn), dtype=torch.uint8, device=self.device))
+        self._chk(self.lib.mpcx_expand_batch(self._ctx, model._h, n, _ptr(nodes), _ptr(out['nbr']), _ptr(out['cost']),
+                                             _ptr(out['collide'])))
+        return out
+
+    def interaction(self, ip: InteractionParams, state, path, path_cs, path_off, path_len, prev_cut_len,
+                    obs6, obs_off, obs_cnt, obs_skip, traj_idx, out=None):
+        """mpcx_interaction_batch. traj_idx updated in place. Returns dict(hit_idx, hit_xy, cut_len)."""
+        Pn = state.shape[0]
+        i32 = torch.int32
+        self._want(state, torch.float64, (Pn, 4), 'state')
+        self._want(path_cs, torch.float64, (path.shape[0], 2), 'path_cs')
+        for nm, t in (('path_off', path_off), ('path_len', path_len), ('obs_off', obs_off), ('obs_cnt', obs_cnt), ('traj_idx', traj_idx)):
+            self._want(t, i32, (Pn,), nm)
+        nobs = 0 if obs6 is None else obs6.shape[0]
+        if out is None:
+            out = dict(hit_idx=torch.empty(Pn, dtype=i32, device=self.device),
+                       hit_xy=torch.empty((Pn, 2), dtype=torch.float64, device=self.device),
+                       cut_len=torch.empty(Pn, dtype=i32, device=self.device))
+        cip = ip.to_c()
+        self._chk(self.lib.mpcx_interaction_batch(self._ctx, C.byref(cip), Pn, _ptr(state), _ptr(path), _ptr(path_cs),
+                                                  _ptr(path_off), _ptr(path_len), _ptr(prev_cut_len), nobs, _ptr(obs6),
+                                                  _ptr(obs_off), _ptr(obs_cnt), _ptr(obs_skip), _ptr(traj_idx),
+                                                  _ptr(out['hit_idx']), _ptr(out['hit_xy']), _ptr(out['cut_len'])))
+        return out
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+
+class SearchModel:
+    """Device copy of the tables `neighbor_function` needs (primitive id = position in the lists given)."""
+
+    def __init__(self, ctx: Context, templates, last_pose, edge_cost, hp, hp_off):
+        self.ctx = ctx
+        tmpl_off = np.cumsum([0] + [len(t) for t in templates]).astype(np.int32)
+        tmpl_xy = np.ascontiguousarray(np.concatenate([np.asarray(t)[:, :2] for t in templates]), np.float64)
+        last_pose = np.ascontiguousarray(last_pose, np.float64)
+        edge_cost = np.ascontiguousarray(edge_cost, np.float64)
+        hp = np.ascontiguousarray(hp, np.float64).reshape(-1, 3)
+        hp_off = np.ascontiguousarray(hp_off, np.int32)
+        self.n_prim = len(templates)
+        self.n_obst = len(hp_off) - 1
+        self.edge_cost = edge_cost
+        vp = C.c_void_p
+        self._h = ctx.lib.mpcx_search_model_create(ctx._ctx, self.n_prim, vp(tmpl_off.ctypes.data), vp(tmpl_xy.ctypes.data),
+                                                   vp(last_pose.ctypes.data), vp(edge_cost.ctypes.data), self.n_obst,
+                                                   vp(hp_off.ctypes.data), vp(hp.ctypes.data))
+        if not self._h:
+            raise MpcxError('mpcx_search_model_create: %s' % ctx.lib.mpcx_last_error(ctx._ctx).decode())
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.ctx.lib.mpcx_search_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,133 @@
+"""GPU parity tests: every kernel of libmpcx.so, called through the C ABI, against the CPU oracle and the
+golden fixtures captured from the reference. Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+QP_TOL = 2e-7      # |u_gpu - u_oracle|, |x_gpu - x_oracle| (north-star bound: 1e-4 vs the reference optimum)
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from mpc_for_av_at_intersection_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _orc():
+    from oracle import oracle_py as orc
+    return orc
+
+
+@pytest.mark.parametrize('T', [10, 13, 20])
+def test_qp_vs_oracle_golden_inputs(ctx, T):
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams
+    orc = _orc()
+    g = H.gold('mpc_pre.npz')
+    ctx.set_mpc_params(MpcParams(T=T))
+    po = orc.MpcParams(T=T)
+    st, xref, xbar, re = g['T%d/state' % T], g['T%d/xref' % T], g['T%d/xbar' % T], g['T%d/reaches_end' % T]
+    out = ctx.qp_solve(ctx.f64(st), ctx.f64(xref), ctx.f64(xbar), ctx.u8(re))
+    ctx.synchronize()
+    u, x = out['u'].cpu().numpy(), out['x'].cpu().numpy()
+    status, iters, kkt = out['status'].cpu().numpy(), out['iters'].cpu().numpy(), out['kkt'].cpu().numpy()
+    assert (status == 0).all(), status
+    du = dx = 0.0
+    for k in range(len(st)):
+        sol = orc.qp_solve(po, st[k], xref[k], xbar[k], re[k])
+        assert sol.status == 0
+        du = max(du, np.abs(sol.u - u[k]).max()); dx = max(dx, np.abs(sol.x - x[k]).max())
+    print('T=%d max|du|=%.3e max|dx|=%.3e iters %d..%d kkt %s' % (T, du, dx, iters.min(), iters.max(), kkt.max(0)))
+    assert du < QP_TOL and dx < QP_TOL
+
+
+def test_qp_warm_start_and_infeasible(ctx):
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams
+    orc = _orc()
+    T = 20
+    g = H.gold('mpc_pre.npz')
+    ctx.set_mpc_params(MpcParams(T=T))
+    po = orc.MpcParams(T=T)
+    st, xref, xbar, re = (g['T20/state'].copy(), g['T20/xref'], g['T20/xbar'], g['T20/reaches_end'])
+    uw = np.stack([g['T20/oa'], g['T20/od']], axis=1)
+    uw[:, 1] = np.clip(uw[:, 1], -0.7, 0.7)
+    st[3, 2] = 9.5        # above MAX_SPEED: x[2,0] <= MAX_SPEED makes the problem infeasible (mpc.py:187)
+    out = ctx.qp_solve(ctx.f64(st), ctx.f64(xref), ctx.f64(xbar), ctx.u8(re), ctx.f64(uw))
+    ctx.synchronize()
+    status = out['status'].cpu().numpy()
+    u = out['u'].cpu().numpy()
+    assert status[3] == 2 and (np.delete(status, 3) == 0).all()
+    for k in (0, 1, 2, 4, 17, 40):
+        sol = orc.qp_solve(po, st[k], xref[k], xbar[k], re[k], uw[k])
+        assert np.abs(sol.u - u[k]).max() < QP_TOL
+
+
+def test_prepare_vs_golden(ctx):
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams
+    g = H.gold('mpc_pre.npz')
+    for T in (10, 13, 20):
+        ctx.set_mpc_params(MpcParams(T=T))
+        st, pc, start = g['T%d/state' % T], g['T%d/path' % T], g['T%d/start' % T]
+        paths, off, ln = [], [], []
+        cur = 0
+        for (sp, ti, cut) in pc:
+            full = H.smoothed_path(sp, ti)
+            paths.append(full); off.append(cur); ln.append(cut); cur += len(full)
+        path = np.concatenate(paths)
+        dl = float(np.linalg.norm(paths[0][0, :2] - paths[0][1, :2]))
+        uw = np.stack([g['T%d/oa' % T], g['T%d/od' % T]], axis=1)
+        tind = ctx.i32(start)
+        out = ctx.prepare(ctx.f64(st), ctx.f64(uw), ctx.f64(path), ctx.i32(off), ctx.i32(ln), dl, tind)
+        ctx.synchronize()
+        assert np.array_equal(tind.cpu().numpy(), g['T%d/target_ind' % T])          # bit-exact index work
+        assert np.array_equal(out['reaches_end'].cpu().numpy(), g['T%d/reaches_end' % T])
+        assert np.array_equal(out['xref'].cpu().numpy(), g['T%d/xref' % T])          # pure gathers: exact
+        d = np.abs(out['xbar'].cpu().numpy() - g['T%d/xbar' % T]).max()
+        assert d < 1e-12, d                                                           # device libm vs numpy sin/cos/tan
+
+
+@pytest.mark.parametrize('tag,version', [('bic', 'bicycle_model'), ('bic1', 'bicycle_model'), ('pri', 'prius')])
+def test_expand_vs_golden(ctx, tag, version):
+    ex = H.gold('expand.npz')
+    sp, ti = ex[tag + '/scenario']
+    model = ctx.search_model(*H.search_tables(version, 'int_%d_%d' % (sp, ti)))
+    nodes = ex[tag + '/nodes']
+    out = ctx.expand(model, ctx.f64(nodes))
+    ctx.synchronize()
+    col = out['collide'].cpu().numpy(); nbr = out['nbr'].cpu().numpy(); cost = out['cost'].cpu().numpy()
+    assert np.array_equal(col, ex[tag + '/collide'])                                  # collide flags bit-exact
+    assert np.abs(nbr - ex[tag + '/nbr']).max() < 1e-12
+    assert np.array_equal(cost, np.broadcast_to(np.array(H.prim_meta(version)['total_length']), cost.shape))
+
+
+def test_interaction_vs_golden(ctx):
+    from mpc_for_av_at_intersection_amd.runtime import InteractionParams
+    mv = H.gold('moving.npz')
+    full = H.gold('mpc_pre.npz')['path_4_1']
+    car = H.car()
+    ip = InteractionParams(cutoff_margin=int(mv['moving/margin']), L=car['L'], radius=car['radius'],
+                           circle_centers=np.array(car['circle_centers']).ravel())
+    n = len(mv['moving/in'])
+    idx = mv['moving/in'][:, 0].astype(np.int32); v0 = mv['moving/in'][:, 1]; nobs = mv['moving/in'][:, 2].astype(np.int32)
+    state = np.zeros((n, 4)); state[:, 0] = full[idx, 0]; state[:, 1] = full[idx, 1]; state[:, 2] = v0
+    pool = np.concatenate([mv['moving/obs'][k][:nobs[k]] for k in range(n)])
+    off = np.concatenate([[0], np.cumsum(nobs)[:-1]]).astype(np.int32)
+    path_cs = np.column_stack([np.cos(full[:, 2]), np.sin(full[:, 2])])
+    # prev_cut_len chosen so that traj_idx is NOT advanced (tmp[traj_idx] == tmp[-1]): the golden cases fix idx
+    prev = (idx + 1).astype(np.int32)
+    tidx = ctx.i32(idx)
+    out = ctx.interaction(ip, ctx.f64(state), ctx.f64(full), ctx.f64(path_cs), ctx.i32(np.zeros(n)), ctx.i32(np.full(n, len(full))),
+                          ctx.i32(prev), ctx.f64(pool), ctx.i32(off), ctx.i32(nobs), None, tidx)
+    ctx.synchronize()
+    hit = out['hit_idx'].cpu().numpy(); xy = out['hit_xy'].cpu().numpy(); cut = out['cut_len'].cpu().numpy()
+    gh = mv['moving/hit']
+    assert np.array_equal(hit, gh[:, 2].astype(np.int32))                             # first conflicting pose: exact
+    assert np.array_equal(cut, mv['moving/cut'])
+    m = hit >= 0
+    assert np.array_equal(xy[m], gh[m, :2])
+    assert np.array_equal(tidx.cpu().numpy(), idx)
