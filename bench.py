@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json: MPC timesteps/s, N=20 horizon, 8-agent intersection.
+
+One "step" = one pass of the hot path over one batch: every (instance, agent) pair of `--batch` instances x 8 agents
+goes through the body of the reference's scenario loop (conflict search + path cut, reference window, rollout, QP,
+plant) -- see mpc_for_av_at_intersection_amd/batch.py.  One *timestep* of the metric = one INSTANCE (all 8 agents)
+advanced by DT = 0.2 s.  Weak scaling: every rank owns `--batch` instances (independent => no data-path
+collective); value = N * batch * steps / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix rate (datasheet; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def qp_flops(T: int, iters: float) -> float:
+    """algorithmic (structure-exploiting) FP64 flops of one agent-QP."""
+    n, m = 2 * T, 8 * T
+    return (16.0 / 3.0) * T ** 3 + 16.0 * T ** 2 + iters * (n ** 3 / 3.0 + 4.0 * n ** 2 + 6.0 * T ** 2 + 12.0 * m)
+
+
+def agent_step_bytes(T: int, A: int) -> float:
+    """algorithmic HBM bytes per agent-step."""
+    return 32 + 16 * T + 48 * (A - 1) + 24 * (T + 1) + 32 * (T + 1) + 16 * T + 8
+
+
+def cpu_baseline(sim, snap_before, n_agents: int):
+    """Oracle (CPU port of the same per-agent step, oracle/) timed on this host, single thread, on a bounded sample
+    of the SAME workload: the first `n_agents` (instance, agent) pairs of rank 0's batch, from the captured state."""
+    from oracle import oracle_py as orc
+    po = orc.MpcParams(T=sim.params.T, L=sim.params.L)
+    tab = sim.path.cpu().numpy(); off = sim.path_off.cpu().numpy(); ln = sim.path_len.cpu().numpy()
+    centers = np.asarray(sim.ip.circle_centers).reshape(2, 2)
+    A = sim.A
+    t0 = time.perf_counter()
+    done = 0
+    for p in range(n_agents):
+        b = p // A
+        others = [q for q in range(b * A, (b + 1) * A) if q != p]
+        st = snap_before['state']; ap = snap_before['applied']
+        obs6 = np.column_stack([st[others][:, [0, 1, 2, 3]], ap[others][:, 1], ap[others][:, 0]])
+        orc.agent_step(po, tab[off[p]:off[p] + ln[p]], sim.dl, st[p], obs6, int(snap_before['traj_idx'][p]),
+                       int(snap_before['prev_cut'][p]), int(snap_before['target_ind'][p]), snap_before['u'][p],
+                       centers, sim.ip.radius, sim.ip.cutoff_margin)
+        done += 1
+        if time.perf_counter() - t0 > 25.0:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=(done / A) / dt, unit='MPC timesteps/s', cores=1, kind='port',
+                sample='%d agent-steps (= %.1f instance timesteps) of rank 0 batch, state after warm-up, oracle/liboracle.so single thread, %.1f s'
+                       % (done, done / A, dt), agent_qp_per_s=done / dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4096, help='scenario instances per GPU')
+    ap.add_argument('--agents', type=int, default=8)
+    ap.add_argument('--horizon', type=int, default=20)
+    ap.add_argument('--cpu-agents', type=int, default=4096, help='agent-steps of the CPU baseline sample (time-capped at 25 s)')
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the hot path is HIP-only')
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+
+    from mpc_for_av_at_intersection_amd.batch import synthetic_batch
+    from mpc_for_av_at_intersection_amd.runtime import Context
+    ctx = Context(local)
+    sim = synthetic_batch(ctx, B=args.batch, A=args.agents, T=args.horizon, seed=1000 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    iters_sum = torch.zeros((), dtype=torch.float64, device=ctx.device)
+    fail_sum = torch.zeros((), dtype=torch.float64, device=ctx.device)
+    for _ in range(args.warmup):
+        sim.step()
+        iters_sum += sim.sol['iters'].sum()          # also warms up the lazily loaded torch reduction kernels
+        fail_sum += (sim.sol['status'] != 0).sum()
+    torch.cuda.synchronize()
+    snap = sim.snapshot() if (rank == 0 and not args.no_cpu) else None
+
+    # HIP events around the dominant kernel (qp_kernel) on the stream it is launched on (= torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    orig_qp = ctx.qp_solve
+    k = [0]
+
+    def timed_qp(*a, **kw):
+        e0, e1 = ev[k[0]]
+        e0.record()
+        r = orig_qp(*a, **kw)
+        e1.record()
+        k[0] += 1
+        return r
+    ctx.qp_solve = timed_qp
+
+    iters_sum.zero_(); fail_sum.zero_()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+        iters_sum += sim.sol['iters'].sum()
+        fail_sum += (sim.sol['status'] != 0).sum()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.qp_solve = orig_qp
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        P = sim.P
+        qp_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        mean_iters = float(iters_sum.item()) / (P * args.steps)
+        flops = qp_flops(args.horizon, mean_iters) * P
+        achieved_tf = flops / (qp_ms * 1e-3) / 1e12
+        bytes_step = agent_step_bytes(args.horizon, args.agents) * P
+        value = world * args.batch * args.steps / elapsed
+        line = {
+            'metric': 'MPC timesteps/sec (whole node), N=20 horizon, 8-agent intersection, batch=4096',
+            'value': value, 'unit': 'MPC timesteps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'configs[2]/[3]: %d-agent coupled stock intersection, batch=%d instances per GPU, N=%d, '
+                                   'interaction (prediction + conflict search + path cut) on-device, seeded staggered starts'
+                                   % (args.agents, args.batch, args.horizon),
+                       'instances_per_gpu': args.batch, 'agents': args.agents, 'horizon': args.horizon,
+                       'parallelism': 'instances sharded over %d GPU(s), no data-path collective' % world},
+            'agent_qp_per_s': value * args.agents,
+            'mean_ipm_iters': mean_iters, 'qp_failures': int(fail_sum.item()),
+            'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved_tf / FP64_PEAK_TFLOPS, 'traffic': None, 'kernel': 'qp_kernel<%d>' % args.horizon,
+                         'kernel_ms': qp_ms, 'flops_per_qp': qp_flops(args.horizon, mean_iters),
+                         'note': 'FP64 compute bound (MI355X FP64 matrix rate == FP64 vector rate, 78.6 TFLOP/s); algorithmic flops of '
+                                 'SURVEY 8(d) x measured mean IPM iterations / HIP-event kernel time; the kernel issues FP64 VALU FMAs, not MFMA'},
+            'roofline_hbm': {'bound': 'hbm', 'achieved': bytes_step / (1e-3 * elapsed / args.steps * 1e3) / 1e9 * 1e3 / 1e3,
+                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'note': 'algorithmic bytes per whole step / step time; not the binding roof'},
+        }
+        line['roofline_hbm']['achieved'] = bytes_step / (elapsed / args.steps) / 1e9
+        line['roofline_hbm']['frac'] = line['roofline_hbm']['achieved'] / HBM_PEAK_GBS
+        if snap is not None:
+            line['cpu_baseline'] = cpu_baseline(sim, snap, min(args.cpu_agents, P))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -128,9 +128,42 @@ int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip,
                                int32_t *traj_idx /*P in-out*/, int32_t *hit_idx /*P*/, double *hit_xy /*P,2*/,
                                int32_t *cut_len /*P*/);
 
+/* ---- lib/collision_avoidance.py:66-104 `check_collision_moving_cars` with the reference's own argument meaning:
+ * problem p has an already-resampled ego trajectory ego_xyyaw[ego_off[p] .. +ego_len[p]) (traj_agent), a detailed
+ * path (path_agent_detailed) and obs_cnt[p] already-predicted obstacle trajectories of exactly ip->pred_steps
+ * poses each, stored as pool entries obs_off[p].. (traj_obstacles; only x, y, yaw are used by the reference).
+ * *_cs = cos/sin of the yaw column, computed by the host.  hit_idx[p] = -1 for None, else the index on the
+ * detailed path (the third element of the reference's return tuple), hit_xy = (x, y). -2 = limits exceeded. */
+int32_t mpcx_moving_collision_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip, int32_t P,
+                                    const double *ego_xyyaw /*ne,3*/, const double *ego_cs /*ne,2*/,
+                                    const int32_t *ego_off /*P*/, const int32_t *ego_len /*P*/,
+                                    const double *path_xyyaw /*np,3*/, const double *path_cs /*np,2*/,
+                                    const int32_t *path_off /*P*/, const int32_t *path_len /*P*/,
+                                    int32_t n_obs_pool, const double *obs_xyyaw /*NOBS,steps,3*/, const double *obs_cs /*NOBS,steps,2*/,
+                                    const int32_t *obs_off /*P*/, const int32_t *obs_cnt /*P*/,
+                                    int32_t *hit_idx /*P*/, double *hit_xy /*P,2*/);
+
+/* ---- lib/linalg.py:4-54 `create_2d_transform_mtx` + `transform_2d_pts` for n_items (pose, point-set) pairs:
+ * item i maps points pts[pts_off[i] .. +pts_cnt[i]) (rows x, y, theta) to world space at nodes[i]; used for
+ * motion_primitive_at / collision_checking_points_at / path_to_full_trajectory
+ * (motion_primitive_search.py:77-85,123-135).  out rows beyond pts_cnt[i] are zero. */
+int32_t mpcx_transform_batch(mpcx_ctx *ctx, int32_t n_items, int32_t max_pts, const double *nodes /*n,3*/,
+                             const int32_t *pts_off /*n*/, const int32_t *pts_cnt /*n*/, const double *pts /*npts,3*/,
+                             double *out /*n,max_pts,3*/);
+
+/* ---- lib/collision_avoidance.py:107-119 `get_cutoff_curve_by_position_idx`: first index of each point list within
+ * `radius` of xy[p]; -1 where the reference would return the input array ("no cutoff"). */
+int32_t mpcx_cutoff_index_batch(mpcx_ctx *ctx, int32_t P, const double *pts /*npts,3*/, const int32_t *off /*P*/,
+                                const int32_t *len /*P*/, const double *xy /*P,2*/, double radius, int32_t *out /*P*/);
+
+/* ---- lib/moving_obstacles_prediction.py:21-47 `state_prediction`: poses (x, y, yaw) of `steps` Euler steps. */
+int32_t mpcx_predict_obstacles_batch(mpcx_ctx *ctx, int32_t n, int32_t steps, double dt, double L,
+                                     const double *obs6 /*n,6*/, double *out_xyyaw /*n,steps,3*/);
+
 /* ---- plant: lib/simulation.py:35-47 `Simulation.step` on B states with the first control of each solution;
- * failed instances (status != 0) get (previous steer, MAX_DECEL) as MPC.step does (mpc.py:294-297). */
-int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state /*B,4 in-out*/, const double *u /*B,2,T*/,
+ * failed instances (status != 0) get (previous steer, MAX_DECEL) as MPC.step does (mpc.py:294-297) and their row of
+ * u is zeroed, which is the warm-start reset of mpc.py:222-224 for the next step. */
+int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state /*B,4 in-out*/, double *u /*B,2,T in-out*/,
                               const int32_t *status /*B or NULL*/, double *applied /*B,2 in-out: (steer, accel)*/);
 
 #ifdef __cplusplus

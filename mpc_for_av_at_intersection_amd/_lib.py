@@ -28,7 +28,8 @@ class InteractionParamsC(C.Structure):
 
 EXPORTS = ['mpcx_create', 'mpcx_destroy', 'mpcx_last_error', 'mpcx_version', 'mpcx_set_mpc_params',
            'mpcx_qp_solve_batch', 'mpcx_mpc_prepare_batch', 'mpcx_search_model_create', 'mpcx_search_model_destroy',
-           'mpcx_expand_batch', 'mpcx_interaction_batch', 'mpcx_plant_step_batch']
+           'mpcx_expand_batch', 'mpcx_interaction_batch', 'mpcx_moving_collision_batch', 'mpcx_plant_step_batch',
+           'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch']
 
 
 def load():
@@ -39,6 +40,8 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('libmpcx.so not built (%s): run `python -c "import __graft_entry__ as g; g.build()"` '
                            'or `make -C mpc_for_av_at_intersection_amd/csrc`; there is no CPU fallback' % LIB_PATH)
+    # torch first: libmpcx.so must bind to the HIP runtime torch ships (same SONAME), not open a second copy
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int32
     lib.mpcx_create.restype = vp; lib.mpcx_create.argtypes = [i32, vp]
@@ -55,6 +58,13 @@ def load():
     lib.mpcx_expand_batch.restype = i32; lib.mpcx_expand_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     lib.mpcx_interaction_batch.restype = i32
     lib.mpcx_interaction_batch.argtypes = [vp, C.POINTER(InteractionParamsC), i32] + [vp] * 6 + [i32] + [vp] * 8
+    lib.mpcx_moving_collision_batch.restype = i32
+    lib.mpcx_moving_collision_batch.argtypes = [vp, C.POINTER(InteractionParamsC), i32] + [vp] * 8 + [i32] + [vp] * 6
     lib.mpcx_plant_step_batch.restype = i32; lib.mpcx_plant_step_batch.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.mpcx_transform_batch.restype = i32; lib.mpcx_transform_batch.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.mpcx_cutoff_index_batch.restype = i32
+    lib.mpcx_cutoff_index_batch.argtypes = [vp, i32, vp, vp, vp, vp, C.c_double, vp]
+    lib.mpcx_predict_obstacles_batch.restype = i32
+    lib.mpcx_predict_obstacles_batch.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
     _lib = lib
     return lib

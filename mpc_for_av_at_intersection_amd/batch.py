@@ -1,0 +1,131 @@
+"""Batched closed loop: B independent intersection instances x A agents advanced in lock-step on one GPU.
+
+One `step()` is the body of the reference's scenario loop (main/scenarios/mpc_intersection.py:95-159) for every
+(instance, agent) pair: nearest index on the full path, ego prediction, prediction of the other agents, conflict
+search and path cut (mpcx_interaction_batch), reference window + warm-start rollout (mpcx_mpc_prepare_batch), the
+QP (mpcx_qp_solve_batch) and the plant update (mpcx_plant_step_batch). Every other agent of the same instance plays
+the role of the reference's `moving_obstacles`: it is described by (x, y, v, yaw, a, steer) exactly like
+`MovingObstacle*.get()` (a, steer = the controls it applied last step). All state lives on the device; a step issues
+five launches and no host synchronisation.
+"""
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .runtime import Context, InteractionParams, MpcParams
+
+
+class IntersectionBatch:
+    def __init__(self, ctx: Context, params: MpcParams, ip: InteractionParams, routes: Sequence[np.ndarray], dl: float,
+                 route_of_agent: np.ndarray, start_index: np.ndarray, v0: Optional[np.ndarray] = None):
+        """routes: list of (n_r, 3) paths whose yaw column is already unwrapped (MPC.__init__, mpc.py:257);
+        route_of_agent, start_index: integer arrays of shape (B, A)."""
+        self.ctx, self.params, self.ip, self.dl = ctx, params, ip, float(dl)
+        ctx.set_mpc_params(params)
+        route_of_agent = np.asarray(route_of_agent, dtype=np.int64)
+        start_index = np.asarray(start_index, dtype=np.int64)
+        self.B, self.A = route_of_agent.shape
+        P = self.P = self.B * self.A
+        T = params.T
+        offs = np.cumsum([0] + [len(r) for r in routes])
+        table = np.concatenate(routes, axis=0).astype(np.float64)
+        self.path = ctx.f64(table)
+        self.path_cs = ctx.f64(np.column_stack([np.cos(table[:, 2]), np.sin(table[:, 2])]))
+        r = route_of_agent.reshape(-1)
+        s = start_index.reshape(-1)
+        self.path_off = ctx.i32(offs[r])
+        self.path_len = ctx.i32(np.array([len(routes[k]) for k in r]))
+        pts = table[offs[r] + s]
+        st = np.zeros((P, 4))
+        st[:, 0], st[:, 1], st[:, 3] = pts[:, 0], pts[:, 1], pts[:, 2]
+        if v0 is not None:
+            st[:, 2] = np.asarray(v0, dtype=np.float64).reshape(-1)
+        dev = ctx.device
+        self.state = ctx.f64(st)
+        self.applied = torch.zeros((P, 2), dtype=torch.float64, device=dev)      # (steer, accel) of the last step
+        self.traj_idx = ctx.i32(s)
+        self.target_ind = ctx.i32(s)
+        self.prev_cut = torch.zeros(P, dtype=torch.int32, device=dev)            # 0 = no tmp_trajectory yet
+        self.obs_off = ctx.i32(np.repeat(np.arange(self.B) * self.A, self.A))
+        self.obs_cnt = torch.full((P,), self.A, dtype=torch.int32, device=dev)
+        self.obs_skip = ctx.i32(np.arange(P))
+        f = torch.float64
+        self.obs6 = torch.zeros((P, 6), dtype=f, device=dev)
+        self.inter = dict(hit_idx=torch.empty(P, dtype=torch.int32, device=dev), hit_xy=torch.empty((P, 2), dtype=f, device=dev),
+                          cut_len=torch.empty(P, dtype=torch.int32, device=dev))
+        self.pre = dict(xref=torch.empty((P, 4, T + 1), dtype=f, device=dev),
+                        reaches_end=torch.empty((P, T + 1), dtype=torch.uint8, device=dev),
+                        xbar=torch.empty((P, 4, T + 1), dtype=f, device=dev))
+        self.sol = dict(x=torch.empty((P, 4, T + 1), dtype=f, device=dev), u=torch.zeros((P, 2, T), dtype=f, device=dev),
+                        status=torch.zeros(P, dtype=torch.int32, device=dev), iters=torch.zeros(P, dtype=torch.int32, device=dev),
+                        kkt=torch.zeros((P, 4), dtype=f, device=dev))
+        self.steps_done = 0
+
+    def step(self):
+        c = self.ctx
+        # what MovingObstacle*.get() would return for every agent: (x, y, v, yaw, a, steer)
+        self.obs6[:, 0:2] = self.state[:, 0:2]
+        self.obs6[:, 2] = self.state[:, 2]
+        self.obs6[:, 3] = self.state[:, 3]
+        self.obs6[:, 4] = self.applied[:, 1]
+        self.obs6[:, 5] = self.applied[:, 0]
+        c.interaction(self.ip, self.state, self.path, self.path_cs, self.path_off, self.path_len,
+                      self.prev_cut if self.steps_done else None, self.obs6, self.obs_off, self.obs_cnt, self.obs_skip,
+                      self.traj_idx, out=self.inter)
+        self.prev_cut.copy_(self.inter['cut_len'])
+        # the previous solution (zeros where the last solve failed or on the first step) is the warm start
+        c.prepare(self.state, self.sol['u'], self.path, self.path_off, self.inter['cut_len'], self.dl, self.target_ind, out=self.pre)
+        c.qp_solve(self.state, self.pre['xref'], self.pre['xbar'], self.pre['reaches_end'], self.sol['u'], out=self.sol)
+        c.plant_step(self.state, self.sol['u'], self.sol['status'], self.applied)
+        self.steps_done += 1
+
+    def snapshot(self):
+        """host copies of the per-agent state (synchronises)"""
+        self.ctx.synchronize()
+        keys = ('state', 'applied', 'traj_idx', 'target_ind', 'prev_cut')
+        out = {k: getattr(self, k).cpu().numpy().copy() for k in keys}
+        out.update({k: v.cpu().numpy().copy() for k, v in self.sol.items()})
+        out.update({k: v.cpu().numpy().copy() for k, v in self.inter.items()})
+        out.update({k: v.cpu().numpy().copy() for k, v in self.pre.items()})
+        return out
+
+
+def stock_routes(ctx: Context, pairs=((1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2))):
+    """Reference paths of the stock 4-way intersection, planned with the GPU-backed MotionPrimitiveSearch
+    (the `_modified` variant every stock MPC scenario uses); yaw columns unwrapped as MPC.__init__ does."""
+    from .lib import _session
+    from .lib.car_dimensions import BicycleModelDimensions
+    from .lib.motion_primitive import load_motion_primitives
+    from .lib.motion_primitive_search_modified import MotionPrimitiveSearch
+    from .lib.mpc import smooth_yaw
+    from .lib.scenario import intersection
+    _session.set_context(ctx)
+    cd = BicycleModelDimensions()
+    mps = load_motion_primitives('bicycle_model')
+    routes = []
+    for sp, ti in pairs:
+        search = MotionPrimitiveSearch(intersection(start_pos=sp, turn_indicator=ti), cd, mps, margin=cd.radius, ctx=ctx)
+        _, _, traj = search.run()
+        traj = np.ascontiguousarray(traj)
+        smooth_yaw(traj[:, 2])
+        routes.append(traj)
+    dl = float(np.linalg.norm(routes[0][0, :2] - routes[0][1, :2]))
+    return routes, dl, cd
+
+
+def synthetic_batch(ctx: Context, B: int, A: int = 8, T: int = 20, seed: int = 0, routes=None, dl=None, cd=None,
+                    max_start_frac: float = 0.35):
+    """B instances x A agents on the stock intersection, one agent per (arm, manoeuvre)
+    route, start positions staggered along the approach (seeded), v0 = 0 as in the reference's scripts."""
+    if routes is None:
+        routes, dl, cd = stock_routes(ctx)
+    rng = np.random.default_rng(seed)
+    R = len(routes)
+    route_of_agent = np.tile(np.arange(A) % R, (B, 1))
+    lens = np.array([len(r) for r in routes])[route_of_agent]
+    start = (rng.random((B, A)) * max_start_frac * lens).astype(np.int64)
+    params = MpcParams(T=T, L=cd.distance_back_to_front_wheel)
+    ip = InteractionParams(cutoff_margin=4 * int(np.ceil(cd.radius / dl)), L=cd.distance_back_to_front_wheel, radius=cd.radius,
+                           circle_centers=np.asarray(cd.circle_centers).ravel())
+    return IntersectionBatch(ctx, params, ip, routes, dl, route_of_agent, start)

@@ -75,6 +75,104 @@ __device__ __forceinline__ int wave_min_i(int v) {
     return v;
 }
 
+// collision_avoidance.py:72-104 on prepared disc tables.  s_ego: ego disc centres of the `na` predicted poses;
+// pred: obstacle disc centres [pool][steps][2][2]; (rem, rcs, n): the detailed path and cos/sin of its yaw.
+// Returns the index of the earliest conflicting pose on the detailed path (and its x,y) or -1 (None).
+__device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)[4], int na, const double *pred,
+                              int ooff, int nobs, int oskip, const double *rem, const double *rcs, int n,
+                              int *s_cand, int lane, double &hx, double &hy) {
+    const double md = 2.0 * ip.radius;
+    const int steps = ip.pred_steps, w = ip.frame_window;
+    double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
+    for (int f = lane; f < na; f += WAVE) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const double ex = s_ego[f][2 * d], ey = s_ego[f][2 * d + 1];
+            bx0 = fmin(bx0, ex); bx1 = fmax(bx1, ex); by0 = fmin(by0, ey); by1 = fmax(by1, ey);
+        }
+    }
+    bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
+    const double slack = md * (1.0 + 1e-9) + 1e-9;      // conservative: never culls a pair within md
+    bx0 -= slack; by0 -= slack; bx1 += slack; by1 += slack;
+
+    // ---- cull obstacle disc positions against the box (exact: a culled disc is farther than md from every ego disc)
+    const int ncand_all = nobs * steps * 2;
+    int cbase = 0;
+    for (int c0 = 0; c0 < ncand_all; c0 += WAVE) {
+        const int cidx = c0 + lane;
+        bool keep = false;
+        if (cidx < ncand_all) {
+            const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;   // o: local obstacle rank
+            int pool = ooff + o;
+            if (oskip >= 0 && pool >= oskip) pool += 1;                                    // skip self
+            const double *q = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
+            keep = (q[0] >= bx0) && (q[0] <= bx1) && (q[1] >= by0) && (q[1] <= by1);
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = cbase + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) s_cand[pos] = cidx;
+        cbase += __popcll(m);
+    }
+    const int ncand = cbase;
+    __syncthreads();
+
+    // ---- exact test of survivors; key = reference row order (frame, agent disc, obstacle, offset, obstacle disc)
+    const int F = na > steps ? na : steps;
+    const long long NOKEY = 0x7fffffffffffffffLL;
+    long long best = NOKEY;
+    const long long npairs = (long long)ncand * F;
+    for (long long q0 = 0; q0 < npairs; q0 += WAVE) {
+        const long long qi = q0 + lane;
+        if (qi < npairs) {
+            const int ci = (int)(qi / F), f = (int)(qi % F);
+            const int cidx = s_cand[ci];
+            const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;
+            const int ff = f < steps ? f : steps - 1;
+            if (abs(g - ff) <= w) {      // some offset d in [-w, w] maps padded frame ff onto obstacle frame g
+                int pool = ooff + o;
+                if (oskip >= 0 && pool >= oskip) pool += 1;
+                const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
+                const double ox = qq[0], oy = qq[1];
+                const int fe = f < na ? f : na - 1;
+#pragma unroll
+                for (int ca = 0; ca < 2; ca++) {
+                    if (dist2d(s_ego[fe][2 * ca], s_ego[fe][2 * ca + 1], ox, oy) <= md) {
+                        // offsets ascend => obstacle frames descend; the first offset reaching g is the one that counts
+                        const long long key = ((((long long)f * 2 + ca) * MPCX_MAX_OBS + o) * MPCX_PRED_STEPS_MAX + (steps - 1 - g)) * 2 + co;
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        }
+    }
+    best = wave_min_ll(best);
+    if (best == NOKEY) return -1;
+    // decode the obstacle disc of the first row
+    const int co = (int)(best & 1);
+    const int g = steps - 1 - (int)((best >> 1) % MPCX_PRED_STEPS_MAX);
+    const int o = (int)(((best >> 1) / MPCX_PRED_STEPS_MAX) % MPCX_MAX_OBS);
+    int pool = ooff + o;
+    if (oskip >= 0 && pool >= oskip) pool += 1;
+    const double ox = pred[((size_t)pool * steps + g) * 4 + 2 * co], oy = pred[((size_t)pool * steps + g) * 4 + 2 * co + 1];
+
+    // ---- collision_avoidance.py:88-104: earliest pose of the detailed path (front-disc block, then rear-disc block)
+    int first = 0x7fffffff;
+    for (int i = lane; i < n; i += WAVE) {
+        const double px = rem[3 * i], py = rem[3 * i + 1], c = rcs[2 * i], s = rcs[2 * i + 1];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
+            const double ex = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
+            const double ey = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
+            if (dist2d(ox, oy, ex, ey) <= md) { const int key = d * n + i; first = key < first ? key : first; }
+        }
+    }
+    first = wave_min_i(first);
+    first = (first == 0x7fffffff) ? 0 : first % n;      // argmax of an all-False mask is 0
+    hx = rem[3 * first]; hy = rem[3 * first + 1];
+    return first;
+}
+
 constexpr int MAXREM = MPCX_MAX_REMAINING;
 constexpr int MAXF = MPCX_EGO_FRAMES_MAX;
 constexpr int MAXCAND = MPCX_MAX_OBS * MPCX_PRED_STEPS_MAX * 2;
@@ -84,7 +182,6 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     __shared__ int s_keep[MAXF];
     __shared__ double s_ego[MAXF][4];     // ego disc centres per kept pose: (x0,y0,x1,y1)
     __shared__ int s_cand[MAXCAND];       // surviving obstacle disc ids: (o*steps + g)*2 + co
-    __shared__ int s_cnt;
 
     const int p = blockIdx.x, lane = threadIdx.x;
     const mpcx_interaction_params &ip = a.ip;
@@ -92,9 +189,6 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     const double *pcs = a.path_cs + 2 * (size_t)a.path_off[p];
     const int len = a.path_len[p];
     const double x = a.state[4 * p], y = a.state[4 * p + 1], v = a.state[4 * p + 2];
-    const double md = 2.0 * ip.radius;
-    const int steps = ip.pred_steps, w = ip.frame_window;
-
     // ---- mpc_intersection.py:103-105: advance traj_agent_idx unless the previous tmp_trajectory collapsed onto it
     int tidx = a.traj_idx[p];
     bool advance = true;
@@ -129,7 +223,6 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     if (lane == 0) {                      // np.cumsum: strictly sequential adds
         double c = 0.0;
         for (int i = 0; i < n; i++) { c = __dadd_rn(c, s_cum[i]); s_cum[i] = c; }
-        s_cnt = 0;
     }
     __syncthreads();
     const bool accel_phase = v < ip.max_speed;
@@ -162,106 +255,25 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     }
     (void)overflow;
     __syncthreads();
-    // ego disc centres per kept pose and their bounding box
-    double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
+    // ego disc centres per kept pose
     for (int f = lane; f < na; f += WAVE) {
         const int i = s_keep[f];
         const double px = rem[3 * i], py = rem[3 * i + 1], c = rcs[2 * i], s = rcs[2 * i + 1];
 #pragma unroll
         for (int d = 0; d < 2; d++) {
             const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
-            const double ex = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
-            const double ey = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
-            s_ego[f][2 * d] = ex; s_ego[f][2 * d + 1] = ey;
-            bx0 = fmin(bx0, ex); bx1 = fmax(bx1, ex); by0 = fmin(by0, ey); by1 = fmax(by1, ey);
+            s_ego[f][2 * d] = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
+            s_ego[f][2 * d + 1] = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
         }
     }
-    bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
-    const double slack = md * (1.0 + 1e-9) + 1e-9;      // conservative: never culls a pair within md
-    bx0 -= slack; by0 -= slack; bx1 += slack; by1 += slack;
     __syncthreads();
-
-    // ---- cull obstacle disc positions against the box; keep ids in reference order-independent form
-    const int ooff = a.obs_off[p], ocnt = a.obs_cnt[p], oskip = a.obs_skip ? a.obs_skip[p] : -1;
-    const int ncand_all = nobs * steps * 2;
-    int cbase = 0;
-    for (int c0 = 0; c0 < ncand_all; c0 += WAVE) {
-        const int cidx = c0 + lane;
-        bool keep = false;
-        if (cidx < ncand_all) {
-            const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;   // o: local obstacle rank
-            int pool = ooff + o;
-            if (oskip >= 0 && pool >= oskip) pool += 1;                                    // skip self
-            const double *q = a.pred + ((size_t)pool * steps + g) * 4 + 2 * co;
-            keep = (q[0] >= bx0) && (q[0] <= bx1) && (q[1] >= by0) && (q[1] <= by1);
-        }
-        const unsigned long long m = __ballot(keep);
-        const int pos = cbase + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) s_cand[pos] = cidx;
-        cbase += __popcll(m);
-    }
-    (void)ocnt;
-    const int ncand = cbase;
-    __syncthreads();
-
-    // ---- exact test of survivors; key = reference row order (frame, agent disc, obstacle, offset, obstacle disc)
-    const int F = na > steps ? na : steps;
-    const long long NOKEY = 0x7fffffffffffffffLL;
-    long long best = NOKEY;
-    const long long npairs = (long long)ncand * F;
-    for (long long q0 = 0; q0 < npairs; q0 += WAVE) {
-        const long long qi = q0 + lane;
-        if (qi < npairs) {
-            const int ci = (int)(qi / F), f = (int)(qi % F);
-            const int cidx = s_cand[ci];
-            const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;
-            const int ff = f < steps ? f : steps - 1;
-            if (abs(g - ff) <= w) {      // some offset d in [-w, w] maps padded frame ff onto obstacle frame g
-                int pool = ooff + o;
-                if (oskip >= 0 && pool >= oskip) pool += 1;
-                const double *qq = a.pred + ((size_t)pool * steps + g) * 4 + 2 * co;
-                const double ox = qq[0], oy = qq[1];
-                const int fe = f < na ? f : na - 1;
-#pragma unroll
-                for (int ca = 0; ca < 2; ca++) {
-                    if (dist2d(s_ego[fe][2 * ca], s_ego[fe][2 * ca + 1], ox, oy) <= md) {
-                        // offsets ascend => obstacle frames descend; first offset reaching g is the one that counts
-                        const long long key = ((((long long)f * 2 + ca) * MPCX_MAX_OBS + o) * MPCX_PRED_STEPS_MAX + (steps - 1 - g)) * 2 + co;
-                        best = key < best ? key : best;
-                    }
-                }
-            }
-        }
-    }
-    best = wave_min_ll(best);
-    if (best == NOKEY) {
+    const int ooff = a.obs_off[p], oskip = a.obs_skip ? a.obs_skip[p] : -1;
+    double hx, hy;
+    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_cand, lane, hx, hy);
+    if (first < 0) {
         if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
     }
-    // decode the obstacle disc of the first row
-    const int co = (int)(best & 1);
-    const int g = steps - 1 - (int)((best >> 1) % MPCX_PRED_STEPS_MAX);
-    const int o = (int)(((best >> 1) / MPCX_PRED_STEPS_MAX) % MPCX_MAX_OBS);
-    int pool = ooff + o;
-    if (oskip >= 0 && pool >= oskip) pool += 1;
-    const double ox = a.pred[((size_t)pool * steps + g) * 4 + 2 * co], oy = a.pred[((size_t)pool * steps + g) * 4 + 2 * co + 1];
-
-    // ---- collision_avoidance.py:88-104: earliest pose of the detailed path (front-disc block, then rear-disc block)
-    int first = 0x7fffffff;
-    for (int i = lane; i < n; i += WAVE) {
-        const double px = rem[3 * i], py = rem[3 * i + 1], c = rcs[2 * i], s = rcs[2 * i + 1];
-#pragma unroll
-        for (int d = 0; d < 2; d++) {
-            const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
-            const double ex = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
-            const double ey = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
-            if (dist2d(ox, oy, ex, ey) <= md) { const int key = d * n + i; first = key < first ? key : first; }
-        }
-    }
-    first = wave_min_i(first);
-    first = (first == 0x7fffffff) ? 0 : first % n;      // argmax of an all-False mask is 0
-    const double hx = rem[3 * first], hy = rem[3 * first + 1];
-
     // ---- collision_avoidance.py:107-119 on trajectory_full, then mpc_intersection.py:130-134
     int cut = 0x7fffffff;
     for (int j = lane; j < len; j += WAVE)
@@ -272,7 +284,68 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = hx; a.hit_xy[2 * p + 1] = hy; a.cut_len[p] = cl; }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// check_collision_moving_cars on EXPLICIT trajectories (the reference's own signature, collision_avoidance.py:66):
+// the caller has already resampled the ego and predicted the obstacles (mpc_intersection.py:110-122).
+struct PoseDiscArgs {
+    mpcx_interaction_params ip;
+    int n;                       // number of poses
+    const double *pose, *cs;     // [n][3] (x,y,yaw), [n][2] (cos,sin of yaw)
+    double *out;                 // [n][4] disc centres
+};
+__global__ __launch_bounds__(256) void pose_disc_kernel(PoseDiscArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const double px = a.pose[3 * i], py = a.pose[3 * i + 1], c = a.cs[2 * i], s = a.cs[2 * i + 1];
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const double cx = a.ip.circle_centers[2 * d], cy = a.ip.circle_centers[2 * d + 1];
+        a.out[4 * i + 2 * d] = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
+        a.out[4 * i + 2 * d + 1] = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
+    }
+}
+
+struct MovArgs {
+    mpcx_interaction_params ip;
+    int P;
+    const double *ego, *ego_cs;
+    const int32_t *ego_off, *ego_len;
+    const double *path, *path_cs;
+    const int32_t *path_off, *path_len;
+    const double *pred;
+    const int32_t *obs_off, *obs_cnt;
+    int32_t *hit_idx;
+    double *hit_xy;
+};
+
+__global__ __launch_bounds__(64) void moving_collision_kernel(MovArgs a) {
+    __shared__ double s_ego[MAXF][4];
+    __shared__ int s_cand[MAXCAND];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const mpcx_interaction_params &ip = a.ip;
+    const int na = a.ego_len[p], n = a.path_len[p], nobs = a.obs_cnt[p];
+    if (nobs <= 0) { if (lane == 0) { a.hit_idx[p] = -1; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; } return; }
+    if (na > MAXF || na < 1 || n < 1 || nobs > MPCX_MAX_OBS) { if (lane == 0) { a.hit_idx[p] = -2; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; } return; }
+    const double *ego = a.ego + 3 * (size_t)a.ego_off[p], *ecs = a.ego_cs + 2 * (size_t)a.ego_off[p];
+    for (int f = lane; f < na; f += WAVE) {
+        const double px = ego[3 * f], py = ego[3 * f + 1], c = ecs[2 * f], s = ecs[2 * f + 1];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
+            s_ego[f][2 * d] = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
+            s_ego[f][2 * d + 1] = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
+        }
+    }
+    __syncthreads();
+    double hx, hy;
+    const int first = first_conflict(ip, s_ego, na, a.pred, a.obs_off[p], nobs, -1,
+                                     a.path + 3 * (size_t)a.path_off[p], a.path_cs + 2 * (size_t)a.path_off[p], n, s_cand, lane, hx, hy);
+    if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = first < 0 ? 0.0 : hx; a.hit_xy[2 * p + 1] = first < 0 ? 0.0 : hy; }
+}
+
 }  // namespace mpcx
+
+static int32_t ensure_pred(mpcx_ctx *ctx, size_t need);
 
 extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip, int32_t P,
                                           const double *state, const double *path_xyyaw, const double *path_cs,
@@ -287,14 +360,7 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
     if (ip->pred_steps < 1 || ip->pred_steps > MPCX_PRED_STEPS_MAX || ip->frame_window < 0 || !(ip->dt > 0) || !(ip->L > 0))
         return mpcx_fail(ctx, MPCX_E_INVALID, "interaction_batch: pred_steps outside 1..%d or bad dt/L/frame_window", MPCX_PRED_STEPS_MAX);
     if (P == 0) return MPCX_OK;
-    const size_t need = (size_t)(n_obs_pool > 0 ? n_obs_pool : 1) * ip->pred_steps * 4;
-    if (need > ctx->pred_cap) {
-        if (ctx->pred) (void)hipFree(ctx->pred);
-        ctx->pred = nullptr; ctx->pred_cap = 0;
-        if (hipMalloc((void **)&ctx->pred, need * sizeof(double)) != hipSuccess)
-            return mpcx_fail(ctx, MPCX_E_LAUNCH, "interaction_batch: cannot allocate %zu bytes of prediction scratch", need * sizeof(double));
-        ctx->pred_cap = need;
-    }
+    { int32_t rc = ensure_pred(ctx, (size_t)(n_obs_pool > 0 ? n_obs_pool : 1) * ip->pred_steps * 4); if (rc != MPCX_OK) return rc; }
     if (n_obs_pool > 0) {
         mpcx::PredArgs pa{*ip, n_obs_pool, obs6, ctx->pred};
         hipLaunchKernelGGL(mpcx::predict_kernel, dim3((n_obs_pool + 255) / 256), dim3(256), 0, ctx->stream, pa);
@@ -303,4 +369,41 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
                        obs_off, obs_cnt, obs_skip, traj_idx, hit_idx, hit_xy, cut_len};
     hipLaunchKernelGGL(mpcx::interaction_kernel, dim3(P), dim3(64), 0, ctx->stream, ia);
     return mpcx_check_launch(ctx, "interaction kernels");
+}
+
+static int32_t ensure_pred(mpcx_ctx *ctx, size_t need) {
+    if (need <= ctx->pred_cap) return MPCX_OK;
+    if (ctx->pred) (void)hipFree(ctx->pred);
+    ctx->pred = nullptr; ctx->pred_cap = 0;
+    if (hipMalloc((void **)&ctx->pred, need * sizeof(double)) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "cannot allocate %zu bytes of prediction scratch", need * sizeof(double));
+    ctx->pred_cap = need;
+    return MPCX_OK;
+}
+
+extern "C" int32_t mpcx_moving_collision_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip, int32_t P,
+                                               const double *ego_xyyaw, const double *ego_cs, const int32_t *ego_off,
+                                               const int32_t *ego_len, const double *path_xyyaw, const double *path_cs,
+                                               const int32_t *path_off, const int32_t *path_len,
+                                               int32_t n_obs_pool, const double *obs_xyyaw, const double *obs_cs,
+                                               const int32_t *obs_off, const int32_t *obs_cnt,
+                                               int32_t *hit_idx, double *hit_xy) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (!ip || P < 0 || n_obs_pool < 0 || !ego_xyyaw || !ego_cs || !ego_off || !ego_len || !path_xyyaw || !path_cs ||
+        !path_off || !path_len || !obs_off || !obs_cnt || !hit_idx || !hit_xy || (n_obs_pool > 0 && (!obs_xyyaw || !obs_cs)))
+        return mpcx_fail(ctx, MPCX_E_INVALID, "moving_collision_batch: null pointer or negative size");
+    if (ip->pred_steps < 1 || ip->pred_steps > MPCX_PRED_STEPS_MAX || ip->frame_window < 0)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "moving_collision_batch: pred_steps outside 1..%d or negative frame_window", MPCX_PRED_STEPS_MAX);
+    if (P == 0) return MPCX_OK;
+    const size_t nposes = (size_t)n_obs_pool * ip->pred_steps;
+    int32_t rc = ensure_pred(ctx, (nposes ? nposes : 1) * 4);
+    if (rc != MPCX_OK) return rc;
+    if (nposes) {
+        mpcx::PoseDiscArgs pd{*ip, (int)nposes, obs_xyyaw, obs_cs, ctx->pred};
+        hipLaunchKernelGGL(mpcx::pose_disc_kernel, dim3((unsigned)((nposes + 255) / 256)), dim3(256), 0, ctx->stream, pd);
+    }
+    mpcx::MovArgs ma{*ip, P, ego_xyyaw, ego_cs, ego_off, ego_len, path_xyyaw, path_cs, path_off, path_len, ctx->pred,
+                     obs_off, obs_cnt, hit_idx, hit_xy};
+    hipLaunchKernelGGL(mpcx::moving_collision_kernel, dim3(P), dim3(64), 0, ctx->stream, ma);
+    return mpcx_check_launch(ctx, "moving collision kernels");
 }

@@ -93,7 +93,7 @@ struct PlantArgs {
     mpcx_mpc_params p;
     int B;
     double *state;
-    const double *u;
+    double *u;
     const int32_t *status;
     double *applied;
 };
@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
     double di = a.applied[2 * b], ai;
     const bool ok = !a.status || a.status[b] == MPCX_QP_OPTIMAL;
     if (ok) { di = a.u[(size_t)b * 2 * T + T]; ai = a.u[(size_t)b * 2 * T]; }
-    else ai = a.p.max_decel;
+    else {
+        ai = a.p.max_decel;
+        for (int t = 0; t < 2 * T; t++) a.u[(size_t)b * 2 * T + t] = 0.0;   // warm start reset, mpc.py:222-224
+    }
     a.applied[2 * b] = di; a.applied[2 * b + 1] = ai;
     double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2], th = a.state[4 * b + 3];
     plant_step(a.p, x, y, v, th, ai, di);
@@ -130,7 +133,7 @@ extern "C" int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double
     return mpcx_check_launch(ctx, "prepare kernels");
 }
 
-extern "C" int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state, const double *u,
+extern "C" int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state, double *u,
                                          const int32_t *status, double *applied) {
     if (!ctx) return MPCX_E_INVALID;
     if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");

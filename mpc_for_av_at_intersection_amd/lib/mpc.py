@@ -1,0 +1,176 @@
+"""Linear time-varying MPC for the kinematic bicycle, GPU-backed (reference: main/lib/mpc.py:13-326).
+
+`MPC(cx, cy, cyaw, dl, car_dimensions, dt).step(state)` keeps the reference's contract: per step it selects the
+reference window (`_calc_ref_trajectory`), rolls the previous solution out through the plant (`_predict_motion`)
+and solves the QP of `_linear_mpc_control` -- here through mpcx_mpc_prepare_batch + mpcx_qp_solve_batch with a
+batch of one. Results are exposed through the same attributes (ox, oy, oyaw, ov, oa, odelta, xref, target_ind,
+di, ai). A failed solve is not an exception: message on stderr, warm start cleared, MAX_DECEL commanded
+(mpc.py:204-206,294-297). For throughput use mpc_for_av_at_intersection_amd.batch.IntersectionBatch instead.
+"""
+import json
+import math
+import os
+import sys
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..runtime import MpcParams
+from ._session import context
+from .simulation import Simulation, State
+
+_CFG = {
+    "NX": 4, "NU": 2, "T": 13, "w_perp": 20.0, "w_para": 1.0, "R": [0.01, 0.01], "Rd": [0.01, 1.0],
+    "Q_v_yaw": [0.0, 0.5], "Qf": [1.0, 1.0, 0.0, 0.5], "GOAL_DIS": 1.5, "STOP_SPEED": 0.1389, "MAX_TIME": 13.0,
+    "MAX_ITER": 1, "DU_TH": 0.1, "MAX_DSTEER": 30.0, "MAX_ACCEL": 2.0, "MAX_DECEL": -10,
+}
+# the reference reads '../config/mpc_config.json' relative to the cwd at import (mpc.py:13); honour it when present
+for _cand in (os.environ.get('MPCX_MPC_CONFIG'), os.path.join('..', 'config', 'mpc_config.json')):
+    if _cand and os.path.exists(_cand):
+        with open(_cand, 'r') as _f:
+            _CFG.update(json.load(_f))
+        break
+
+NX = _CFG['NX']
+NU = _CFG['NU']
+T = _CFG['T']
+w_perp = _CFG['w_perp']
+w_para = _CFG['w_para']
+R = np.diag(_CFG['R'])
+Rd = np.diag(_CFG['Rd'])
+Q_v_yaw = np.diag(_CFG['Q_v_yaw'])
+Qf = np.diag(_CFG['Qf']) * T
+GOAL_DIS = _CFG['GOAL_DIS']
+STOP_SPEED = _CFG['STOP_SPEED']
+MAX_TIME = _CFG['MAX_TIME']
+MAX_ITER = _CFG['MAX_ITER']
+DU_TH = _CFG['DU_TH']
+MAX_DSTEER = np.deg2rad(_CFG['MAX_DSTEER'])
+MAX_ACCEL = _CFG['MAX_ACCEL']
+MAX_DECEL = _CFG['MAX_DECEL']
+
+
+class MPCSolutionNotFoundException(Exception):
+    pass
+
+
+def smooth_yaw(yaw):
+    """unwrap in place so consecutive samples differ by less than pi/2 (mpc.py:43-55); mutates the caller's array"""
+    for i in range(len(yaw) - 1):
+        d = yaw[i + 1] - yaw[i]
+        while d >= math.pi / 2.0:
+            yaw[i + 1] -= math.pi * 2.0
+            d = yaw[i + 1] - yaw[i]
+        while d <= -math.pi / 2.0:
+            yaw[i + 1] += math.pi * 2.0
+            d = yaw[i + 1] - yaw[i]
+    return yaw
+
+
+def _params(car_dimensions, dt) -> MpcParams:
+    """module-level constants are read at call time, like the reference's functions do"""
+    g = globals()
+    Tn = int(g['T'])
+    qf = np.diag(np.asarray(g['Qf'], dtype=float)) / Tn if Tn else np.zeros(4)
+    return MpcParams(T=Tn, dt=float(dt), L=float(car_dimensions.distance_back_to_front_wheel),
+                     w_perp=float(g['w_perp']), w_para=float(g['w_para']), R=tuple(np.diag(g['R'])), Rd=tuple(np.diag(g['Rd'])),
+                     Q_v_yaw=tuple(np.diag(g['Q_v_yaw'])), Qf_base=tuple(qf), max_speed=float(Simulation.MAX_SPEED),
+                     min_speed=float(Simulation.MIN_SPEED), max_accel=float(g['MAX_ACCEL']), max_decel=float(g['MAX_DECEL']),
+                     max_steer=float(Simulation.MAX_STEER), max_dsteer=float(g['MAX_DSTEER']))
+
+
+class MPC:
+    def __init__(self, cx: np.ndarray, cy: np.ndarray, cyaw: np.ndarray, dl: float, car_dimensions, dt: float = 0.2, ctx=None):
+        self.cx = cx
+        self.cy = cy
+        self.cyaw = smooth_yaw(cyaw)         # in place: the caller's array is unwrapped too (mpc.py:257)
+        self.dl = dl
+        self.dt = dt
+        self.car_dimensions = car_dimensions
+        self.goal: Tuple[float, float] = cx[-1], cy[-1]
+        self.target_ind: int = 0
+        self.odelta: Optional[np.ndarray] = None
+        self.oa: Optional[np.ndarray] = None
+        self.ox = self.oy = self.oyaw = self.ov = None
+        self.xref = None
+        self.di: float = 0.0
+        self.ai: float = 0.0
+        self.status = 0
+        self.iters = 0
+        self.kkt = None
+        self._ctx = ctx if ctx is not None else context()
+        self._dev_path = None
+        self._dev_key = None
+        self._upload()
+
+    # ------------------------------------------------------------------ path residency
+    def _key(self):
+        a = self.cx
+        return (a.__array_interface__['data'][0], a.strides, self.cy.__array_interface__['data'][0],
+                self.cyaw.__array_interface__['data'][0])
+
+    def _upload(self):
+        path = np.column_stack([self.cx, self.cy, self.cyaw]).astype(np.float64)
+        self._dev_path = self._ctx.f64(path)
+        self._dev_key = self._key()
+        self._dev_len = len(path)
+        self._host_path = path
+
+    def set_trajectory_fromarray(self, trajectory: np.ndarray):
+        self.cx = trajectory[:, 0]
+        self.cy = trajectory[:, 1]
+        self.cyaw = trajectory[:, 2]
+        # the usual case is a prefix of the resident path (trajectory_full[:k]): only the length changes
+        n = len(self.cx)
+        if not (self._key() == self._dev_key and n <= self._dev_len
+                and np.array_equal(self._host_path[:n, 0], self.cx) and np.array_equal(self._host_path[:n, 2], self.cyaw)):
+            self._upload()
+
+    # ------------------------------------------------------------------ one control step (mpc.py:280-299)
+    def step(self, state: State) -> Tuple[float, float]:
+        ctx = self._ctx
+        p = _params(self.car_dimensions, self.dt)
+        if ctx.params != p:
+            ctx.set_mpc_params(p)
+        Tn = p.T
+        x0 = ctx.f64([[state.x, state.y, state.v, state.yaw]])
+        warm = None
+        if self.oa is not None and self.odelta is not None:
+            warm = ctx.f64(np.stack([np.asarray(self.oa, float), np.asarray(self.odelta, float)])[None])
+        tind = ctx.i32([self.target_ind])
+        pre = ctx.prepare(x0, warm, self._dev_path, ctx.i32([0]), ctx.i32([len(self.cx)]), float(self.dl), tind)
+        sol = ctx.qp_solve(x0, pre['xref'], pre['xbar'], pre['reaches_end'], warm)
+        ctx.synchronize()
+        ti = int(tind.cpu()[0])
+        if ti < 0:
+            raise Exception("something wrong")             # trajectories.py:120
+        self.target_ind = ti
+        self.xref = pre['xref'].cpu().numpy()[0]
+        self.status = int(sol['status'].cpu()[0]); self.iters = int(sol['iters'].cpu()[0])
+        self.kkt = sol['kkt'].cpu().numpy()[0]
+        if self.status == 0:
+            x = sol['x'].cpu().numpy()[0]; u = sol['u'].cpu().numpy()[0]
+            self.ox, self.oy, self.ov, self.oyaw = x[0].copy(), x[1].copy(), x[2].copy(), x[3].copy()
+            self.oa, self.odelta = u[0].copy(), u[1].copy()
+            self.di, self.ai = self.odelta[0], self.oa[0]
+        else:
+            print("Error: Cannot solve mpc...", file=sys.stderr)
+            self.oa = self.odelta = self.ox = self.oy = self.oyaw = self.ov = None
+            self.ai = MAX_DECEL
+        return self.di, self.ai
+
+    def get_current_xref_deviation(self):
+        """reproduces the reference's component-wise formula verbatim (mpc.py:301-308)"""
+        ref = np.array([self.cx[self.target_ind], self.cy[self.target_ind]])
+        true = np.array([self.ox[0], self.oy[0]])
+        ang = self.cyaw[self.target_ind] + np.pi / 2
+        d = ref - true
+        return np.linalg.norm(np.array([np.cos(ang) * d[0], np.sin(ang) * d[1]]))
+
+    def is_goal(self, state: State) -> bool:
+        d = math.hypot(state.x - self.goal[0], state.y - self.goal[1])
+        near = d <= GOAL_DIS
+        if abs(self.target_ind - len(self.cx)) >= 5:
+            near = False
+        return bool(near and abs(state.v) <= STOP_SPEED)

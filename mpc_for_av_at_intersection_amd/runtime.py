@@ -211,6 +211,40 @@ class Context:
                                                   _ptr(out['hit_idx']), _ptr(out['hit_xy']), _ptr(out['cut_len'])))
         return out
 
+    def moving_collision(self, ip: InteractionParams, ego, ego_cs, ego_off, ego_len, path, path_cs, path_off, path_len,
+                         obs, obs_cs, obs_off, obs_cnt, out=None):
+        """mpcx_moving_collision_batch (explicit trajectories). Returns dict(hit_idx, hit_xy)."""
+        Pn = ego_off.shape[0]
+        if out is None:
+            out = dict(hit_idx=torch.empty(Pn, dtype=torch.int32, device=self.device),
+                       hit_xy=torch.empty((Pn, 2), dtype=torch.float64, device=self.device))
+        nobs = 0 if obs is None else obs.shape[0]
+        cip = ip.to_c()
+        self._chk(self.lib.mpcx_moving_collision_batch(self._ctx, C.byref(cip), Pn, _ptr(ego), _ptr(ego_cs), _ptr(ego_off),
+                                                       _ptr(ego_len), _ptr(path), _ptr(path_cs), _ptr(path_off), _ptr(path_len),
+                                                       nobs, _ptr(obs), _ptr(obs_cs), _ptr(obs_off), _ptr(obs_cnt),
+                                                       _ptr(out['hit_idx']), _ptr(out['hit_xy'])))
+        return out
+
+    def transform(self, nodes, pts_off, pts_cnt, pts, max_pts):
+        """mpcx_transform_batch -> (n, max_pts, 3)"""
+        n = nodes.shape[0]
+        out = torch.empty((n, max_pts, 3), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.mpcx_transform_batch(self._ctx, n, int(max_pts), _ptr(nodes), _ptr(pts_off), _ptr(pts_cnt), _ptr(pts), _ptr(out)))
+        return out
+
+    def cutoff_index(self, pts, off, ln, xy, radius=0.001):
+        Pn = off.shape[0]
+        out = torch.empty(Pn, dtype=torch.int32, device=self.device)
+        self._chk(self.lib.mpcx_cutoff_index_batch(self._ctx, Pn, _ptr(pts), _ptr(off), _ptr(ln), _ptr(xy), C.c_double(radius), _ptr(out)))
+        return out
+
+    def predict_obstacles(self, obs6, steps, dt, L):
+        n = obs6.shape[0]
+        out = torch.empty((n, steps, 3), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.mpcx_predict_obstacles_batch(self._ctx, n, int(steps), C.c_double(dt), C.c_double(L), _ptr(obs6), _ptr(out)))
+        return out
+
     def synchronize(self):
         self.stream.synchronize()
 

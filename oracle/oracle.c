@@ -271,6 +271,8 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
     int32_t m = orc_qp_build(p, x0, xref, xbar, re, H, g, G, h, S, c);
     int32_t status = ORC_MAXITER, it = 0;
     double res_d = 0, res_p = 0, mu = 0;
+    const double tol_loose = p->tol > 1e-7 ? p->tol : 1e-7;
+    int loose = 0;
 
     /* x[2,0] bounds are constant rows (mpc.py:187-188 include t=0) */
     if (x0[2] > p->max_speed + 1e-9 || x0[2] < p->min_speed - 1e-9) { status = ORC_INFEASIBLE; goto done; }
@@ -302,7 +304,10 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
         }
         mu /= m;
         if (res_d <= p->tol * gnorm && res_p <= p->tol * hnorm && mu <= p->tol) { status = ORC_OK; break; }
-        if (it == p->max_iter) break;
+        /* reduced-accuracy acceptance when the iteration cannot continue (the reference accepts ECOS's
+         * OPTIMAL_INACCURATE too, mpc.py:196) */
+        loose = (res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose);
+        if (it == p->max_iter) { if (loose) status = ORC_OK; break; }
         /* M = H + G' D G */
         memcpy(M, H, sizeof(double) * n * n);
         for (int i = 0; i < m; i++) {
@@ -314,7 +319,7 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
                 for (int b = 0; b <= a; b++) M[a * n + b] += da * Gi[b];
             }
         }
-        if (chol(M, n)) { status = ORC_NUMERIC; break; }
+        if (chol(M, n)) { status = loose ? ORC_OK : ORC_NUMERIC; break; }
         /* predictor */
         for (int i = 0; i < m; i++) w[i] = -lam[i] + (lam[i] / s[i]) * rp[i];   /* (-rc + lam*rp)/s with rc = s*lam */
         for (int k = 0; k < n; k++) { double a = -rd[k]; for (int i = 0; i < m; i++) a -= G[i * n + k] * w[i]; du[k] = a; }
@@ -333,7 +338,7 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
         double sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
         /* corrector */
         for (int i = 0; i < m; i++) {
-            rc[i] = s[i] * lam[i] + dsa[i] * dla[i] - sigma * mu;
+            rc[i] = s[i] * lam[i] + alpha * (dsa[i] * dla[i]) - sigma * mu;   /* second-order term damped by the affine step length */
             w[i] = (-rc[i] + lam[i] * rp[i]) / s[i];
         }
         for (int k = 0; k < n; k++) { double a = -rd[k]; for (int i = 0; i < m; i++) a -= G[i * n + k] * w[i]; du[k] = a; }

@@ -285,3 +285,47 @@ def a_star(start, is_goal, heuristic, neighbors, max_expansions=10 ** 7):
             if seen is None or ng < seen[0]:
                 heapq.heappush(heap, (ng + heuristic(nb), ng, nb, node))
     raise Exception("No solution found.")
+
+
+# ---------------------------------------------------------------- one closed-loop step of one ego
+def agent_step(p: MpcParams, full, dl, state4, obs6, traj_idx, prev_cut, target_ind, u_warm, centers, radius,
+               cutoff_margin, pred_steps=35, frame_window=20, max_accel=2.0):
+    """The body of main/scenarios/mpc_intersection.py:95-159 for one ego, on the oracle's C functions.
+    full: (n,3) path with unwrapped yaw; obs6: (K,6) other vehicles; prev_cut: length of the previous tmp_trajectory
+    (0/None = none yet); u_warm: (2,T) previous solution or None. Returns a dict with every intermediate."""
+    full = np.ascontiguousarray(full, np.float64)
+    x, y, v, yaw = state4
+    # :103-105 advance traj_agent_idx unless tmp_trajectory collapsed onto it
+    advance = True
+    if prev_cut:
+        advance = bool(np.any(full[traj_idx] != full[prev_cut - 1]))
+    if advance:
+        traj_idx = nearest_index_in_direction(x, y, full[:, 0], full[:, 1], traj_idx)
+        if traj_idx < 0:
+            raise Exception("something wrong")
+    traj = full[traj_idx:]
+    # :110-116 ego prediction
+    if v < p.max_speed:
+        rdl = np.cumsum(np.zeros(len(traj)) + max_accel) + v
+        rdl = p.dt * np.minimum(rdl, p.max_speed)
+        tres = resample_curve(traj, rdl)
+    else:
+        tres = resample_curve(traj, p.dt * p.max_speed)
+    # :119-122 predictions of the others, :125-136 conflict + cut
+    trajs = [predict_obstacle(s6, p.dt, p.L, pred_steps) for s6 in obs6]
+    hit = check_collision_moving_cars(centers, radius, tres, traj, trajs, frame_window)
+    if hit is not None:
+        cut = cutoff_idx(full, hit[0], hit[1]) - cutoff_margin
+        cut = max(traj_idx + 1, cut)
+    else:
+        cut = len(full)
+    tmp = full[:cut]
+    # mpc.py:211-239
+    xref, target_ind, re = calc_ref_trajectory(p, state4, tmp[:, 0], tmp[:, 1], tmp[:, 2], dl, target_ind)
+    if target_ind < 0:
+        raise Exception("something wrong")
+    uw = np.zeros((2, p.T)) if u_warm is None else np.asarray(u_warm, float)
+    xbar = predict_motion(p, [x, y, v, yaw], uw[0], uw[1])
+    sol = qp_solve(p, [x, y, v, yaw], xref, xbar, re, uw)
+    return dict(traj_idx=traj_idx, hit=hit, cut=cut, target_ind=target_ind, xref=xref, xbar=xbar, re=re, sol=sol,
+                n_res=len(tres))

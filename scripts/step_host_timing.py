@@ -1,0 +1,54 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mpc_for_av_at_intersection_amd.batch import synthetic_batch
+from mpc_for_av_at_intersection_amd.runtime import Context
+ctx = Context(0)
+sim = synthetic_batch(ctx, B=4096, A=8, T=20, seed=1000)
+for _ in range(3): sim.step()
+torch.cuda.synchronize()
+c = sim.ctx
+for rep in range(3):
+    t = [time.perf_counter()]
+    sim.obs6[:, 0:2] = sim.state[:, 0:2]; sim.obs6[:, 2] = sim.state[:, 2]; sim.obs6[:, 3] = sim.state[:, 3]
+    sim.obs6[:, 4] = sim.applied[:, 1]; sim.obs6[:, 5] = sim.applied[:, 0]
+    t.append(time.perf_counter())
+    c.interaction(sim.ip, sim.state, sim.path, sim.path_cs, sim.path_off, sim.path_len, sim.prev_cut, sim.obs6, sim.obs_off, sim.obs_cnt, sim.obs_skip, sim.traj_idx, out=sim.inter)
+    t.append(time.perf_counter())
+    sim.prev_cut.copy_(sim.inter['cut_len'])
+    t.append(time.perf_counter())
+    c.prepare(sim.state, sim.sol['u'], sim.path, sim.path_off, sim.inter['cut_len'], sim.dl, sim.target_ind, out=sim.pre)
+    t.append(time.perf_counter())
+    c.qp_solve(sim.state, sim.pre['xref'], sim.pre['xbar'], sim.pre['reaches_end'], sim.sol['u'], out=sim.sol)
+    t.append(time.perf_counter())
+    c.plant_step(sim.state, sim.sol['u'], sim.sol['status'], sim.applied)
+    t.append(time.perf_counter())
+    torch.cuda.synchronize()
+    t.append(time.perf_counter())
+    print(['%.3f' % ((b - a) * 1e3) for a, b in zip(t[:-1], t[1:])])
+t0 = time.perf_counter()
+for _ in range(9): sim.step()
+x0_last = None
+orig_plant = c.plant_step
+def _pl(state, u, status, applied):
+    global x0_last, uw_last
+    x0_last = state.clone()
+    return orig_plant(state, u, status, applied)
+c.plant_step = _pl
+orig_qp = c.qp_solve
+def _qp(x0, xref, xbar, re, uw, out=None):
+    global uw_last
+    uw_last = uw.clone()
+    return orig_qp(x0, xref, xbar, re, uw, out=out)
+c.qp_solve = _qp
+sim.step()
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print('10 steps: host issue %.2f ms, total %.2f ms' % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+st = sim.sol['status'].cpu().numpy(); it = sim.sol['iters'].cpu().numpy(); k = sim.sol['kkt'].cpu().numpy()
+import numpy as np
+print('status counts', np.bincount(st), 'iters of failures', it[st != 0][:20], k[st != 0][:5], sim.state.cpu().numpy()[st != 0][:5])
+bad = np.nonzero(st != 0)[0]
+os.makedirs('gpurun_out', exist_ok=True)
+# re-run the failing problems' inputs: the pre tensors are those of the last step
+np.savez('gpurun_out/qp_fail.npz', idx=bad, status=st[bad], x0=x0_last.cpu().numpy()[bad], uw=uw_last.cpu().numpy()[bad], xref=sim.pre['xref'].cpu().numpy()[bad],
+         xbar=sim.pre['xbar'].cpu().numpy()[bad], re=sim.pre['reaches_end'].cpu().numpy()[bad], u=sim.sol['u'].cpu().numpy()[bad])
