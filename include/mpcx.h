@@ -86,7 +86,10 @@ int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double *state /*B
 
 /* ---- lib/motion_primitive_search.py:87-121 `neighbor_function` (+ obstacles.py:157-176 `check_collision`,
  * linalg.py:4-54, maths.py:4-10).  Model tables are copied to the device once by mpcx_search_model_create
- * (HOST pointers there).  primitive id = index in the arrays given (callers use sorted names). */
+ * (HOST pointers there).  primitive id = index in the arrays given (callers use sorted names).
+ * A* nodes are compared by exact float equality and ordered by exact f-values (a_star.py:34-49): a search that must
+ * replay the reference's pop order passes nodes_cs computed by the host's numpy (what linalg.py:4-22 calls), which
+ * makes successor coordinates bit-identical to the reference; bulk expansion passes NULL. */
 typedef struct mpcx_search_model mpcx_search_model;
 mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_prim,
                                             const int32_t *tmpl_off /*n_prim+1*/, const double *tmpl_xy /*npts,2*/,
@@ -94,6 +97,7 @@ mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_prim,
                                             int32_t n_obst, const int32_t *hp_off /*n_obst+1*/, const double *hp /*rows,3*/);
 void mpcx_search_model_destroy(mpcx_search_model *m);
 int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, int32_t n_nodes, const double *nodes /*n,3*/,
+                          const double *nodes_cs /*n,2: cos,sin of nodes[:,2], or NULL = device sincos*/,
                           double *nbr /*n,P,3*/, double *cost /*n,P*/, uint8_t *collide /*n,P*/);
 
 /* ---- lib/collision_avoidance.py:66-119 `check_collision_moving_cars` + `get_cutoff_curve_by_position_idx`,

@@ -55,7 +55,7 @@ def load():
     lib.mpcx_search_model_create.restype = vp
     lib.mpcx_search_model_create.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.mpcx_search_model_destroy.restype = None; lib.mpcx_search_model_destroy.argtypes = [vp]
-    lib.mpcx_expand_batch.restype = i32; lib.mpcx_expand_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    lib.mpcx_expand_batch.restype = i32; lib.mpcx_expand_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     lib.mpcx_interaction_batch.restype = i32
     lib.mpcx_interaction_batch.argtypes = [vp, C.POINTER(InteractionParamsC), i32] + [vp] * 6 + [i32] + [vp] * 8
     lib.mpcx_moving_collision_batch.restype = i32

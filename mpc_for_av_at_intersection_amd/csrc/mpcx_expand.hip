@@ -25,7 +25,7 @@ constexpr int EXP_MAX_OBST = 128;
 struct ExpandArgs {
     int n_prim, n_obst, n_pts, n_rows, n_nodes;
     const int32_t *tmpl_off, *hp_off;
-    const double *tmpl_xy, *last_pose, *edge_cost, *hp, *nodes;
+    const double *tmpl_xy, *last_pose, *edge_cost, *hp, *nodes, *nodes_cs;
     double *nbr, *cost;
     uint8_t *collide;
 };
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) {
     const int node = (int)(gid / a.n_prim), k = (int)(gid % a.n_prim);
     const double x = a.nodes[3 * node], y = a.nodes[3 * node + 1], th = a.nodes[3 * node + 2];
     double s, c;
-    sincos(th, &s, &c);
+    if (a.nodes_cs) { c = a.nodes_cs[2 * node]; s = a.nodes_cs[2 * node + 1]; }   // host-supplied cos/sin (bit-identical to numpy)
+    else sincos(th, &s, &c);
     const bool rot_only = (x == 0.0 && y == 0.0);     // linalg.py:13-17
     const double tx = rot_only ? 0.0 : x, ty = rot_only ? 0.0 : y;
 
@@ -138,13 +139,13 @@ extern "C" void mpcx_search_model_destroy(mpcx_search_model *m) {
 }
 
 extern "C" int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, int32_t n_nodes, const double *nodes,
-                                     double *nbr, double *cost, uint8_t *collide) {
+                                     const double *nodes_cs, double *nbr, double *cost, uint8_t *collide) {
     if (!ctx) return MPCX_E_INVALID;
     if (!m || n_nodes < 0 || !nodes || !nbr || !cost || !collide)
         return mpcx_fail(ctx, MPCX_E_INVALID, "expand_batch: null pointer or negative node count");
     if (n_nodes == 0) return MPCX_OK;
     mpcx::ExpandArgs a{m->n_prim, m->n_obst, m->n_pts, m->n_rows, n_nodes, m->d_tmpl_off, m->d_hp_off,
-                       m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_hp, nodes, nbr, cost, collide};
+                       m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_hp, nodes, nodes_cs, nbr, cost, collide};
     const long long total = (long long)n_nodes * m->n_prim;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(mpcx::expand_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);

@@ -132,8 +132,11 @@ class MotionPrimitiveSearch:
         nodes = [n for n in dict.fromkeys(nodes) if n not in self._cache]
         if not nodes:
             return []
-        dev = self._ctx.f64(np.array(nodes, dtype=np.float64).reshape(-1, 3))
-        out = self._ctx.expand(self._model, dev)
+        arr = np.array(nodes, dtype=np.float64).reshape(-1, 3)
+        # cos/sin from the host's numpy -- the library the reference's create_2d_transform_mtx calls -- so successor
+        # coordinates (hence exact-equality node identity and exact-tie pop order) are bit-identical to the reference
+        cs = np.column_stack([np.cos(arr[:, 2]), np.sin(arr[:, 2])])
+        out = self._ctx.expand(self._model, self._ctx.f64(arr), nodes_cs=self._ctx.f64(cs))
         self.kernel_launches += 1
         nbr = out['nbr'].cpu().numpy()
         col = out['collide'].cpu().numpy()

@@ -44,9 +44,10 @@ class CircleObstacle(Obstacle):
     def to_convex(self, margin: float = 0.) -> np.ndarray:
         cx, cy = self.xy_center
         r = self.radius
-        d = r * np.sqrt(2) + 2 * margin      # the reference's (un-normalised) diagonal offset, obstacles.py:145-148
+        q, m2 = r * np.sqrt(2), 2 * margin   # the reference's (un-normalised) diagonal offset, obstacles.py:145-148;
+        # subtracted one after the other, left to right, so the rows round exactly like the reference's
         return np.array([[1, 0, -(cx + r + margin)], [-1, 0, cx - r - margin], [0, 1, -(cy + r + margin)], [0, -1, cy - r - margin],
-                         [-1, 1, cx - cy - d], [1, -1, -cx + cy - d], [-1, -1, cx + cy - d], [1, 1, -cx - cy - d]])
+                         [-1, 1, cx - cy - q - m2], [1, -1, -cx + cy - q - m2], [-1, -1, cx + cy - q - m2], [1, 1, -cx - cy - q - m2]])
 
     def distance_to_point(self, point) -> float:
         px, py = point

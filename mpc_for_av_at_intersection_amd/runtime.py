@@ -177,16 +177,19 @@ class Context:
     def search_model(self, templates, last_pose, edge_cost, hp, hp_off):
         return SearchModel(self, templates, last_pose, edge_cost, hp, hp_off)
 
-    def expand(self, model: 'SearchModel', nodes, out=None):
-        """mpcx_expand_batch: nodes (n,3) -> dict(nbr (n,P,3), cost (n,P), collide (n,P) uint8)."""
+    def expand(self, model: 'SearchModel', nodes, out=None, nodes_cs=None):
+        """mpcx_expand_batch: nodes (n,3) -> dict(nbr (n,P,3), cost (n,P), collide (n,P) uint8).
+        nodes_cs (n,2): optional host-computed cos/sin of the headings (bit-exact replay of the reference's search)."""
         n = nodes.shape[0]
         self._want(nodes, torch.float64, (n, 3), 'nodes')
+        if nodes_cs is not None:
+            self._want(nodes_cs, torch.float64, (n, 2), 'nodes_cs')
         Pn = model.n_prim
         if out is None:
             out = dict(nbr=torch.empty((n, Pn, 3), dtype=torch.float64, device=self.device),
                        cost=torch.empty((n, Pn), dtype=torch.float64, device=self.device),
                        collide=torch.empty((n, Pn), dtype=torch.uint8, device=self.device))
-        self._chk(self.lib.mpcx_expand_batch(self._ctx, model._h, n, _ptr(nodes), _ptr(out['nbr']), _ptr(out['cost']),
+        self._chk(self.lib.mpcx_expand_batch(self._ctx, model._h, n, _ptr(nodes), _ptr(nodes_cs), _ptr(out['nbr']), _ptr(out['cost']),
                                              _ptr(out['collide'])))
         return out
 

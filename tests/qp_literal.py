@@ -1,0 +1,104 @@
+"""Literal (un-condensed) restatement of the QP of main/lib/mpc.py:138-208, written against the reference source:
+variables z = [x(4,T+1) column-major by time ; u(2,T)], objective exactly as the cvxpy expression sums it, equality and
+inequality rows as the constraints list.  Used only to certify oracle/GPU solutions (KKT of THIS problem) and to
+cross-check against scipy; it shares no code with oracle.c or the HIP kernel."""
+import math
+
+import numpy as np
+
+
+def build(p, x0, xref, xbar, reaches_end):
+    """returns P, q, c0 (objective z'Pz + q'z + c0), Aeq, beq, G, h and index helpers ix(i,t), iu(j,t)"""
+    T = p.T
+    nz = 4 * (T + 1) + 2 * T
+
+    def ix(i, t):
+        return 4 * t + i
+
+    def iu(j, t):
+        return 4 * (T + 1) + 2 * t + j
+    P = np.zeros((nz, nz)); q = np.zeros(nz); c0 = 0.0
+    Aeq, beq, G, h = [], [], [], []
+    Qf = np.diag([v * T for v in p.Qf_base])
+    for t in range(T + 1):
+        if t > 0:
+            if not reaches_end[t]:
+                for ang, w in ((xref[3, t] + 0.5 * np.pi, p.w_perp), (xref[3, t], p.w_para)):
+                    c, s = np.cos(ang), np.sin(ang)
+                    M = np.array([[c ** 2, c * s], [c * s, s ** 2]]) * w
+                    r = xref[:2, t]
+                    idx = [ix(0, t), ix(1, t)]
+                    P[np.ix_(idx, idx)] += M; q[idx] += -2 * M @ r; c0 += r @ M @ r
+                Mq = np.diag(p.Q_v_yaw); r = xref[2:, t]; idx = [ix(2, t), ix(3, t)]
+                P[np.ix_(idx, idx)] += Mq; q[idx] += -2 * Mq @ r; c0 += r @ Mq @ r
+            else:
+                r = xref[:, t]; idx = [ix(i, t) for i in range(4)]
+                P[np.ix_(idx, idx)] += Qf; q[idx] += -2 * Qf @ r; c0 += r @ Qf @ r
+        if t < T:
+            v, phi, delta, dt, L = xbar[2, t], xbar[3, t], 0.0, p.dt, p.L
+            A = np.eye(4)
+            A[0, 2] = dt * math.cos(phi); A[0, 3] = -dt * v * math.sin(phi)
+            A[1, 2] = dt * math.sin(phi); A[1, 3] = dt * v * math.cos(phi)
+            A[3, 2] = dt * math.tan(delta) / L
+            B = np.zeros((4, 2)); B[2, 0] = dt; B[3, 1] = dt * v / (L * math.cos(delta) ** 2)
+            C = np.array([dt * v * math.sin(phi) * phi, -dt * v * math.cos(phi) * phi, 0.0, -dt * v * delta / (L * math.cos(delta) ** 2)])
+            for i in range(4):      # x[:, t+1] == A x[:, t] + B u[:, t] + C
+                row = np.zeros(nz); row[ix(i, t + 1)] = 1.0
+                for j in range(4):
+                    row[ix(j, t)] -= A[i, j]
+                for j in range(2):
+                    row[iu(j, t)] -= B[i, j]
+                Aeq.append(row); beq.append(C[i])
+            Rt = np.diag(p.R_end) if reaches_end[t] else np.diag(p.R)
+            idx = [iu(0, t), iu(1, t)]
+            P[np.ix_(idx, idx)] += Rt
+        if t < T - 1:
+            Rd = np.diag(p.Rd)
+            for j in range(2):
+                a, b = iu(j, t + 1), iu(j, t)
+                P[a, a] += Rd[j, j]; P[b, b] += Rd[j, j]; P[a, b] -= Rd[j, j]; P[b, a] -= Rd[j, j]
+            for sgn in (1.0, -1.0):  # |u[1,t+1] - u[1,t]| <= MAX_DSTEER * dt
+                row = np.zeros(nz); row[iu(1, t + 1)] = sgn; row[iu(1, t)] = -sgn
+                G.append(row); h.append(p.max_dsteer * p.dt)
+    for i in range(4):              # x[:, 0] == x0
+        row = np.zeros(nz); row[ix(i, 0)] = 1.0
+        Aeq.append(row); beq.append(x0[i])
+    for t in range(T + 1):
+        row = np.zeros(nz); row[ix(2, t)] = 1.0; G.append(row); h.append(p.max_speed)
+        row = np.zeros(nz); row[ix(2, t)] = -1.0; G.append(row); h.append(-p.min_speed)
+    for t in range(T):
+        row = np.zeros(nz); row[iu(0, t)] = 1.0; G.append(row); h.append(p.max_accel)
+        row = np.zeros(nz); row[iu(0, t)] = -1.0; G.append(row); h.append(-p.max_decel)
+        row = np.zeros(nz); row[iu(1, t)] = 1.0; G.append(row); h.append(p.max_steer)
+        row = np.zeros(nz); row[iu(1, t)] = -1.0; G.append(row); h.append(p.max_steer)
+    return P, q, c0, np.array(Aeq), np.array(beq), np.array(G), np.array(h), ix, iu
+
+
+def pack(p, x, u):
+    T = p.T
+    return np.concatenate([np.asarray(x).T.reshape(-1), np.asarray(u).T.reshape(-1)])
+
+
+def kkt_certificate(p, x0, xref, xbar, reaches_end, x, u):
+    """KKT residuals of the literal problem at (x,u): equality violation, inequality violation, and the best
+    multipliers: min || 2Pz + q + Aeq' nu + G' lam ||  over nu free, lam >= 0 (NNLS over ALL inequality rows); a KKT
+    point needs stat ~ 0 and comp = max lam_i * slack_i ~ 0."""
+    from scipy.optimize import nnls
+    P, q, c0, Aeq, beq, G, h, _, _ = build(p, x0, xref, xbar, reaches_end)
+    z = pack(p, x, u)
+    eq = np.abs(Aeq @ z - beq).max()
+    slack = h - G @ z
+    ineq = max(0.0, float((-slack).max()))
+    grad = 2 * P @ z + q
+    # rows with visible slack cannot carry a multiplier at a KKT point: penalise them so NNLS prefers tight rows
+    pen = 1e3 * np.maximum(slack, 0.0)
+    M = np.concatenate([np.concatenate([Aeq.T, -Aeq.T, G.T], axis=1),
+                        np.concatenate([np.zeros((len(h), 2 * len(beq))), np.diag(pen)], axis=1)], axis=0)
+    scale = max(1.0, np.abs(grad).max())
+    rhs = np.concatenate([-grad / scale, np.zeros(len(h))])
+    sol, _ = nnls(M / scale * 1.0, rhs, maxiter=50 * M.shape[1])
+    lam = sol[2 * len(beq):] * 1.0
+    nu = sol[:len(beq)] - sol[len(beq):2 * len(beq)]
+    stat = np.abs(grad + Aeq.T @ nu * 1.0 + G.T @ lam).max()
+    comp = float((lam * np.maximum(slack, 0.0)).max())
+    return dict(eq=eq, ineq=ineq, stat=stat, comp=comp, obj=float(z @ P @ z + q @ z + c0), grad_scale=scale)

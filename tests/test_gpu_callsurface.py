@@ -1,0 +1,174 @@
+"""GPU tests of the reference's Python call surface (mpc_for_av_at_intersection_amd.lib.*) against golden runs of the
+reference: full A* searches (cost, primitive ids and expansion ORDER exact, coordinates <= 1e-12) and the stock
+closed loop of main/scenarios/mpc_intersection.py (integer decisions exact, states within a stated tolerance)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+COORD_TOL = 1e-12
+
+
+def _setup(version='bicycle_model'):
+    from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions, PriusDimensions
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive import load_motion_primitives
+    cd = BicycleModelDimensions() if version == 'bicycle_model' else PriusDimensions()
+    return cd, load_motion_primitives(version)
+
+
+def _check_run(search, runs, pre, names_sorted):
+    cost, path, traj = search.run(debug=True)
+    assert cost == float(runs[pre + 'cost'])
+    gp = runs[pre + 'path']
+    assert len(path) == len(gp) and np.abs(np.array(path) - gp).max() < COORD_TOL
+    seq = [names_sorted.index(search._points_to_mp_names[a, b]) for a, b in zip(path[:-1], path[1:])]
+    assert seq == runs[pre + 'seq'].tolist()                                  # primitive ids: exact
+    dbg = search.debug_data
+    assert len(dbg) == len(runs[pre + 'dbg_g'])                               # same number of expansions ...
+    assert np.abs(np.array([d.node for d in dbg]) - runs[pre + 'dbg_node']).max() < COORD_TOL     # ... in the same order
+    assert np.array_equal(np.array([d.g for d in dbg]), runs[pre + 'dbg_g'])
+    assert np.abs(np.array([d.h for d in dbg]) - runs[pre + 'dbg_h']).max() < 1e-11
+    assert traj.shape == runs[pre + 'traj'].shape and np.abs(traj - runs[pre + 'traj']).max() < COORD_TOL
+    return search
+
+
+@pytest.mark.parametrize('sp,ti', [(sp, ti) for sp in (1, 2, 3, 4) for ti in (1, 2, 3)])
+def test_search_modified_all_stock_routes(sp, ti):
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive_search_modified import MotionPrimitiveSearch
+    from mpc_for_av_at_intersection_amd.lib.scenario import intersection
+    cd, mps = _setup()
+    s = MotionPrimitiveSearch(intersection(turn_indicator=ti, start_pos=sp), cd, mps, margin=cd.radius)
+    _check_run(s, H.gold('astar_runs.npz'), 'mod_bic_%d_%d/' % (sp, ti), sorted(mps))
+    assert s.kernel_launches < len(s.debug_data) + 2          # batching: fewer launches than expansions
+
+
+@pytest.mark.parametrize('variant,pre,sp,ti,kw', [
+    ('base', 'base_bic_4_1/', 4, 1, {}), ('base', 'base_bic_3_2/', 3, 2, {}), ('base', 'base_bic_2_3/', 2, 3, {}),
+    ('multi_lane', 'ml_bic_4_1/', 4, 1, {}), ('multi_lane', 'ml_bic_1_2/', 1, 2, {}),
+    ('multi_lane', 'mlw_bic_4_1/', 4, 1, dict(wh_obstacle=0.2, wh_center=0.1, wc_center=0.05))])
+def test_search_other_variants(variant, pre, sp, ti, kw):
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive_search import MotionPrimitiveSearch
+    from mpc_for_av_at_intersection_amd.lib.scenario import intersection
+    cd, mps = _setup()
+    s = MotionPrimitiveSearch(intersection(turn_indicator=ti, start_pos=sp), cd, mps, margin=cd.radius, variant=variant, **kw)
+    _check_run(s, H.gold('astar_runs.npz'), pre, sorted(mps))
+
+
+def test_search_prius_and_geometry_helpers():
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive_search_modified import MotionPrimitiveSearch
+    from mpc_for_av_at_intersection_amd.lib.scenario import intersection
+    cd, mps = _setup('prius')
+    runs = H.gold('astar_runs.npz')
+    if 'mod_pri_4_1/cost' in runs.files:
+        s = MotionPrimitiveSearch(intersection(turn_indicator=1, start_pos=4), cd, mps, margin=cd.radius)
+        _check_run(s, runs, 'mod_pri_4_1/', sorted(mps))
+    cd, mps = _setup()
+    s = MotionPrimitiveSearch(intersection(turn_indicator=1, start_pos=4), cd, mps, margin=cd.radius)
+    ex = H.gold('expand.npz')
+    node = tuple(ex['bic/nodes'][7].tolist())
+    pts = s.motion_primitive_at('left2', node)
+    assert pts.shape == mps['left2'].points.shape
+    k = sorted(mps).index('left2')
+    assert np.abs(pts[-1, :2] - ex['bic/nbr'][7, k, :2]).max() < 1e-12       # last point == successor pose
+    cc = s.collision_checking_points_at('left2', node)
+    assert cc.shape == (10, 3)
+    with pytest.raises(Exception, match='No solution found'):
+        from mpc_for_av_at_intersection_amd.lib.obstacles import BoxObstacle
+        sc = intersection(turn_indicator=1, start_pos=4)
+        sc.obstacles.append(BoxObstacle(xy_width=(200, 200), height=1, xy_center=(0, 0)))   # everything blocked
+        MotionPrimitiveSearch(sc, cd, mps, margin=cd.radius).run()
+
+
+def test_check_collision_and_linalg_functions():
+    from mpc_for_av_at_intersection_amd.lib.linalg import create_2d_transform_mtx, transform_2d_pts
+    from mpc_for_av_at_intersection_amd.lib.obstacles import BoxObstacle, CircleObstacle, check_collision
+    box = BoxObstacle(xy_width=(2, 4), height=1, xy_center=(1, 1)).to_convex(margin=0.5)
+    assert check_collision(box, np.array([[5.0, 2.4], [5.0, 3.4]])) is True
+    assert check_collision(box, np.array([[5.0, 2.6], [5.0, 3.4]])) is False
+    circ = CircleObstacle(radius=1.0, height=1, xy_center=(0, 0)).to_convex(margin=0.0)
+    assert circ.shape == (8, 3) and check_collision(circ, np.array([[0.6], [0.6]])) is True
+    assert check_collision(circ, np.array([[0.8], [0.8]])) is False          # outside the octagon's diagonal row
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(7, 3))
+    for cfg in ((1.0, -2.0, 0.7), (0.0, 0.0, -1.1)):
+        m = create_2d_transform_mtx(*cfg)
+        out = transform_2d_pts(cfg[2], m, pts)
+        c, s = np.cos(cfg[2]), np.sin(cfg[2])
+        ref = np.column_stack([c * pts[:, 0] - s * pts[:, 1] + cfg[0], s * pts[:, 0] + c * pts[:, 1] + cfg[1], pts[:, 2] + cfg[2]])
+        assert np.abs(out - ref).max() < 1e-14
+
+
+@pytest.mark.parametrize('T', [10, 13, 20])
+def test_stock_closed_loop_matches_reference_run(T):
+    """main/scenarios/mpc_intersection.py:95-159 driven with the product classes; golden = the reference's own loop with
+    the oracle QP substituted for ECOS (tests/golden/make_golden.py --stage closedloop)."""
+    import mpc_for_av_at_intersection_amd.lib.mpc as pmpc
+    from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions
+    from mpc_for_av_at_intersection_amd.lib.collision_avoidance import check_collision_moving_cars, get_cutoff_curve_by_position_idx
+    from mpc_for_av_at_intersection_amd.lib.moving_obstacles_prediction import MovingObstaclesPrediction
+    from mpc_for_av_at_intersection_amd.lib.simulation import HistorySimulation, Simulation, State
+    from mpc_for_av_at_intersection_amd.lib.trajectories import calc_nearest_index_in_direction, resample_curve
+    g = H.gold('closedloop.npz')
+    tape = H.gold('moving.npz')['traffic/tape']
+    pmpc.T = T
+    pmpc.Qf = np.diag([1.0, 1.0, 0.0, 0.5]) * T
+    try:
+        DT = 0.2
+        cd = BicycleModelDimensions()
+        full = H.gold('mpc_pre.npz')['path_4_1'].copy()
+        dl = np.linalg.norm(full[0, :2] - full[1, :2])
+        mpc = pmpc.MPC(cx=full[:, 0], cy=full[:, 1], cyaw=full[:, 2], dl=dl, dt=DT, car_dimensions=cd)
+        assert np.array_equal(full, g['T%d/full' % T])            # smooth_yaw mutated the caller's array like the reference
+        state = State(x=full[0, 0], y=full[0, 1], yaw=full[0, 2], v=0.0)
+        sim = HistorySimulation(car_dimensions=cd, sample_time=DT, initial_state=state)
+        margin = 4 * int(np.ceil(cd.radius / dl))
+        tidx, tmp = 0, None
+        n_steps = int(g['T%d/steps' % T])
+        worst = 0.0
+        for i in range(n_steps):
+            assert not mpc.is_goal(state)
+            assert np.abs(np.array([state.x, state.y, state.v, state.yaw]) - g['T%d/state' % T][i]).max() < 1e-6
+            worst = max(worst, np.abs(np.array([state.x, state.y, state.v, state.yaw]) - g['T%d/state' % T][i]).max())
+            if tmp is None or np.any(tmp[tidx, :] != tmp[-1, :]):
+                tidx = calc_nearest_index_in_direction(state, full[:, 0], full[:, 1], start_index=tidx, forward=True)
+            assert tidx == g['T%d/tidx' % T][i]
+            tres = traj = full[tidx:]
+            if state.v < Simulation.MAX_SPEED:
+                rdl = DT * np.minimum(np.cumsum(np.zeros(tres.shape[0]) + pmpc.MAX_ACCEL) + state.v, Simulation.MAX_SPEED)
+                tres = resample_curve(tres, dl=rdl)
+            else:
+                tres = resample_curve(tres, dl=DT * Simulation.MAX_SPEED)
+            trajs = [np.vstack(MovingObstaclesPrediction(*six, sample_time=DT, car_dimensions=cd).state_prediction(7.)).T for six in tape[i]]
+            hit = check_collision_moving_cars(cd, tres, traj, trajs, frame_window=20)
+            if hit is not None:
+                cut = max(tidx + 1, get_cutoff_curve_by_position_idx(full, hit[0], hit[1]) - margin)
+                tmp = full[:cut]
+                assert hit[2] == g['T%d/hit' % T][i][2] and cut == g['T%d/cut' % T][i]
+            else:
+                tmp = full
+                assert g['T%d/hit' % T][i][2] < 0
+            mpc.set_trajectory_fromarray(tmp)
+            delta, acc = mpc.step(state)
+            assert mpc.status == 0 and mpc.target_ind == g['T%d/target' % T][i]
+            assert np.abs(np.array([delta, acc]) - g['T%d/ctrl' % T][i]).max() < 1e-6
+            assert np.abs(mpc.xref - g['T%d/xref' % T][i]).max() == 0.0
+            state = sim.step(a=acc, delta=delta, xref_deviation=mpc.get_current_xref_deviation())
+        assert mpc.is_goal(state)
+        print('T=%d closed loop: %d steps, worst state deviation %.2e' % (T, n_steps, worst))
+    finally:
+        pmpc.T = 13
+        pmpc.Qf = np.diag([1.0, 1.0, 0.0, 0.5]) * 13
+
+
+def test_mpc_failure_path_commands_max_decel(capsys):
+    import mpc_for_av_at_intersection_amd.lib.mpc as pmpc
+    from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions
+    from mpc_for_av_at_intersection_amd.lib.simulation import State
+    full = H.gold('mpc_pre.npz')['path_4_1'].copy()
+    mpc = pmpc.MPC(cx=full[:, 0], cy=full[:, 1], cyaw=full[:, 2], dl=0.083, dt=0.2, car_dimensions=BicycleModelDimensions())
+    d0, a0 = mpc.step(State(x=full[0, 0], y=full[0, 1], yaw=full[0, 2], v=1.0))
+    assert mpc.status == 0
+    d1, a1 = mpc.step(State(x=full[3, 0], y=full[3, 1], yaw=full[3, 2], v=9.5))    # v > MAX_SPEED: infeasible (mpc.py:187)
+    assert mpc.status == 2 and a1 == pmpc.MAX_DECEL and d1 == d0 and mpc.oa is None and mpc.odelta is None
+    assert 'Cannot solve mpc' in capsys.readouterr().err

@@ -101,7 +101,12 @@ def test_expand_vs_golden(ctx, tag, version):
     ctx.synchronize()
     col = out['collide'].cpu().numpy(); nbr = out['nbr'].cpu().numpy(); cost = out['cost'].cpu().numpy()
     assert np.array_equal(col, ex[tag + '/collide'])                                  # collide flags bit-exact
-    assert np.abs(nbr - ex[tag + '/nbr']).max() < 1e-12
+    assert np.abs(nbr - ex[tag + "/nbr"]).max() < 1e-12
+    cs = np.column_stack([np.cos(nodes[:, 2]), np.sin(nodes[:, 2])])
+    out2 = ctx.expand(model, ctx.f64(nodes), nodes_cs=ctx.f64(cs))
+    ctx.synchronize()
+    assert np.array_equal(out2["nbr"].cpu().numpy(), ex[tag + "/nbr"])            # host trig: bit-exact successors
+    assert np.array_equal(out2["collide"].cpu().numpy(), ex[tag + "/collide"])
     assert np.array_equal(cost, np.broadcast_to(np.array(H.prim_meta(version)['total_length']), cost.shape))
 
 

@@ -1,0 +1,168 @@
+"""CPU tests of the host-side logic of the product (no GPU needed): C-ABI library exports, the reference call surface's
+host parts (A* queue, set-up geometry, heuristics) against the golden vectors, and the multi-GPU sharding rule."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mpc_for_av_at_intersection_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    hdr = open(os.path.join(ROOT, 'include', 'mpcx.h')).read()
+    declared = sorted(set(re.findall(r'\b(mpcx_[a-z_0-9]+)\s*\(', hdr)))
+    assert len(declared) >= 16
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.EXPORTS) == declared
+    lib.mpcx_version.restype = ctypes.c_char_p
+    assert b'gfx950' in lib.mpcx_version()
+
+
+def test_struct_layouts_match_header():
+    from mpc_for_av_at_intersection_amd import _lib
+    assert ctypes.sizeof(_lib.MpcParamsC) == 8 + 8 * 23          # 2 int32 + 23 doubles, no padding surprises
+    assert ctypes.sizeof(_lib.InteractionParamsC) == 16 + 8 * 9
+    from oracle import oracle_py as orc
+    assert ctypes.sizeof(orc._CParams) == ctypes.sizeof(_lib.MpcParamsC)
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    from mpc_for_av_at_intersection_amd.runtime import Context, MpcxError
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(MpcxError):
+        Context(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'mpc_for_av_at_intersection_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dp, f)).read()
+                assert 'oracle' not in src.replace('oracle/', '').lower() or f in (), (dp, f)
+
+
+def test_a_star_class_matches_reference_unit_vectors():
+    from mpc_for_av_at_intersection_amd.lib.a_star import AStar
+    edges = {'Start': [('A', 3), ('B', 1), ('D', 4)], 'A': [('C', 2)], 'B': [('A', 4), ('H', 1), ('E', 6)],
+             'C': [('F', 1), ('Goal', 9)], 'D': [('L', 2)], 'E': [('J', 4)], 'F': [('G', 1)], 'G': [('K', 3)],
+             'H': [('G', 4), ('I', 6), ('O', 2)], 'I': [('J', 5)], 'J': [('G', 3), ('Goal', 3)], 'K': [('N', 1)],
+             'M': [('K', 1), ('Goal', 2)], 'N': [('M', 2)], 'O': [('L', 2)], 'L': [], 'Goal': []}
+    a = AStar(lambda n: ((w, m) for m, w in edges[n]))
+    g, path = a.run('Start', lambda n: n == 'Goal', lambda n: 0, debug=True)
+    assert g == 14 and path == ['Start', 'A', 'C', 'Goal']
+    assert [(d.node, d.g, d.predecessor) for d in a.debug_data] == [
+        ('Start', 0, 'Start'), ('B', 1, 'Start'), ('H', 2, 'B'), ('A', 3, 'Start'), ('D', 4, 'Start'), ('O', 4, 'H'),
+        ('C', 5, 'A'), ('F', 6, 'C'), ('G', 6, 'H'), ('L', 6, 'D'), ('E', 7, 'B'), ('I', 8, 'H'), ('K', 9, 'G'),
+        ('N', 10, 'K'), ('J', 11, 'E'), ('M', 12, 'N'), ('Goal', 14, 'C')]
+    b = AStar(lambda n: ((1., n + d) for d in (-1, 1)))
+    b.run(0, lambda n: n == 10, lambda n: 0, debug=True)
+    assert len(b.debug_data) == 21
+    b.run(0, lambda n: n == 10, lambda n: abs(n - 10), debug=True)
+    assert len(b.debug_data) == 11
+    with pytest.raises(Exception, match='No solution found'):
+        AStar(lambda n: iter(())).run(0, lambda n: False, lambda n: 0)
+    # peek_open never changes results
+    c = AStar(lambda n: (c.peek_open(5) and None) or ((1., n + d) for d in (-1, 1)))
+    assert c.run(0, lambda n: n == 4, lambda n: abs(n - 4))[0] == 4
+
+
+def test_setup_geometry_matches_golden():
+    from mpc_for_av_at_intersection_amd.lib import car_dimensions as cdm
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive import load_motion_primitives
+    from mpc_for_av_at_intersection_amd.lib.scenario import intersection
+    from mpc_for_av_at_intersection_amd.lib.trajectories import car_trajectory_to_collision_point_trajectories, resample_curve
+    tm, sc, prim = H.gold('templates.npz'), H.gold('scenarios.npz'), H.gold('primitives.npz')
+    for version, cd in (('bicycle_model', cdm.BicycleModelDimensions()), ('prius', cdm.PriusDimensions())):
+        ref = H.car(version)
+        assert cd.radius == ref['radius'] and cd.distance_back_to_front_wheel == ref['L']
+        assert np.array_equal(cd.circle_centers, np.array(ref['circle_centers']))
+        mps = load_motion_primitives(version)
+        assert sorted(mps) == H.prim_meta(version)['names']
+        for n, mp in mps.items():
+            assert np.array_equal(mp.points, prim['%s/%s' % (version, n)])
+            pts = resample_curve(mp.points.copy(), dl=cd.radius, keep_last_point=True)
+            tpl = np.concatenate(car_trajectory_to_collision_point_trajectories(pts, cd), axis=0)
+            assert np.array_equal(tpl, tm['%s/%s' % (version, n)])            # G2: collision templates bit-exact
+        tag = 'bic' if version == 'bicycle_model' else 'pri'
+        for sp in (1, 2, 3, 4):
+            for ti in (1, 2, 3):
+                s = intersection(turn_indicator=ti, start_pos=sp)
+                key = 'int_%d_%d' % (sp, ti)
+                hp = np.concatenate([o.to_convex(margin=cd.radius) for o in s.obstacles], axis=0)
+                assert np.array_equal(hp, sc[key + '/hp_' + tag])             # G3: half-plane rows bit-exact
+                assert s.start == tuple(sc[key + '/start']) and s.goal_point == tuple(sc[key + '/goal_point'])
+
+
+def test_host_path_utilities_match_golden():
+    from mpc_for_av_at_intersection_amd.lib.simulation import State
+    from mpc_for_av_at_intersection_amd.lib.trajectories import calc_nearest_index_in_direction, resample_curve
+    from mpc_for_av_at_intersection_amd.lib.mpc import smooth_yaw
+    from mpc_for_av_at_intersection_amd.lib.maths import normalize_angle
+    mv, pre = H.gold('moving.npz'), H.gold('mpc_pre.npz')
+    full = pre['path_4_1']
+    for (x, y, s), o in zip(mv['nearest/in'], mv['nearest/out']):
+        assert calc_nearest_index_in_direction(State(x=x, y=y), full[:, 0], full[:, 1], start_index=int(s)) == o
+    for k in range(6):
+        v0, i0 = mv['resample/%d/in' % k]
+        tr = full[int(i0):]
+        assert np.array_equal(resample_curve(tr, dl=H.ego_resample_dl(len(tr), v0)), mv['resample/%d/out' % k])
+    assert np.array_equal(smooth_yaw(pre['smooth_yaw/in'].copy()), pre['smooth_yaw/out'])
+    assert normalize_angle(-1e-17) == 0.0 and normalize_angle(np.pi) == -np.pi and abs(normalize_angle(7.0) - (7.0 - 2 * np.pi)) < 1e-15
+
+
+def test_plant_matches_oracle():
+    from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions
+    from mpc_for_av_at_intersection_amd.lib.simulation import Simulation, State
+    from oracle import oracle_py as orc
+    rng = np.random.default_rng(0)
+    p = orc.MpcParams(T=5)
+    for _ in range(50):
+        st = [rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(-5, 8.3), rng.uniform(-4, 4)]
+        a, d = rng.uniform(-12, 4), rng.uniform(-1.2, 1.2)
+        sim = Simulation(BicycleModelDimensions(), 0.2, State(x=st[0], y=st[1], v=st[2], yaw=st[3]))
+        o = sim.step(a, d)
+        ref = orc.plant_step(p, st, a, d)
+        assert np.abs(np.array([o.x, o.y, o.v, o.yaw]) - ref).max() < 1e-13
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mpc_for_av_at_intersection_amd.sharding import shard_instances, gather_agent_states
+    import torch
+    lo, hi = shard_instances(10, rank, world)
+    local = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1, 1).repeat(1, 3, 6) + 0.5 * rank * 0
+    allst = gather_agent_states(local, 10, rank, world)
+    q.put((rank, lo, hi, allst[:, 0, 0].tolist()))
+    dist.destroy_process_group()
+
+
+def test_sharding_world_size_2_gloo():
+    """instances shard contiguously; the optional agent-state exchange (north-star's all-gather) reassembles them"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p_ in procs:
+        p_.join(60)
+    assert res[0][1:3] == (0, 5) and res[1][1:3] == (5, 10)
+    for r in res:
+        assert r[3] == [float(i) for i in range(10)]

@@ -1,0 +1,63 @@
+"""CPU tests of the oracle's QP (oracle.c:orc_qp_solve): the reference's solver (cvxpy -> ECOS, mpc.py:193-194) cannot
+run in this pipeline, so parity of the SOLVE is 'unpinned' by reference outputs; these tests certify every oracle
+solution against the literal un-condensed problem restated from mpc.py:138-208 (tests/qp_literal.py) -- strictly
+convex => unique minimiser => a KKT point IS the answer any correct solver (ECOS included) converges to -- and
+cross-check a subset against scipy's SLSQP."""
+import numpy as np
+import pytest
+
+from oracle import oracle_py as orc
+from tests import helpers as H
+from tests import qp_literal as QL
+
+
+@pytest.mark.parametrize('T', [10, 13, 20])
+def test_kkt_certificate_of_literal_problem(T):
+    g = H.gold('mpc_pre.npz')
+    p = orc.MpcParams(T=T)
+    for k in range(0, 60, 3):
+        st, xref, xbar, re = g['T%d/state' % T][k], g['T%d/xref' % T][k], g['T%d/xbar' % T][k], g['T%d/reaches_end' % T][k]
+        sol = orc.qp_solve(p, st, xref, xbar, re)
+        assert sol.status == 0
+        c = QL.kkt_certificate(p, st, xref, xbar, re, sol.x, sol.u)
+        assert c['eq'] < 1e-9, c            # dynamics + initial state rows of mpc.py:175,186
+        assert c['ineq'] < 1e-9, c          # bounds of mpc.py:184-191
+        assert c['stat'] < 1e-6 * c['grad_scale'], c     # stationarity with multipliers >= 0 ...
+        assert c['comp'] < 1e-6 * c['grad_scale'], c     # ... that vanish on rows with slack
+
+
+def test_against_scipy_slsqp():
+    from scipy.optimize import minimize
+    g = H.gold('mpc_pre.npz')
+    T = 10
+    p = orc.MpcParams(T=T)
+    for k in (2, 11, 20, 33):
+        st, xref, xbar, re = g['T10/state'][k], g['T10/xref'][k], g['T10/xbar'][k], g['T10/reaches_end'][k]
+        sol = orc.qp_solve(p, st, xref, xbar, re)
+        P, q, c0, Aeq, beq, G, h, _, _ = QL.build(p, st, xref, xbar, re)
+        z0 = QL.pack(p, np.tile(st[:, None], (1, T + 1)), np.zeros((2, T)))
+        r = minimize(lambda z: z @ P @ z + q @ z + c0, z0, jac=lambda z: 2 * P @ z + q, method='SLSQP',
+                     constraints=[{'type': 'eq', 'fun': lambda z: Aeq @ z - beq, 'jac': lambda z: Aeq},
+                                  {'type': 'ineq', 'fun': lambda z: h - G @ z, 'jac': lambda z: -G}],
+                     options={'maxiter': 500, 'ftol': 1e-14})
+        zo = QL.pack(p, sol.x, sol.u)
+        fo = zo @ P @ zo + q @ zo + c0
+        assert fo <= r.fun + 1e-6 * max(1.0, abs(r.fun))          # the oracle is at least as good as SLSQP
+        assert np.abs(zo - r.x).max() < 1e-3                        # and lands on the same point (SLSQP accuracy)
+
+
+def test_status_codes_and_warm_start():
+    g = H.gold('mpc_pre.npz')
+    p = orc.MpcParams(T=20)
+    st = g['T20/state'][4].copy()
+    args = (g['T20/xref'][4], g['T20/xbar'][4], g['T20/reaches_end'][4])
+    cold = orc.qp_solve(p, st, *args)
+    warm = orc.qp_solve(p, st, *args, u_warm=np.stack([np.clip(g['T20/oa'][4], -10, 2), np.clip(g['T20/od'][4], -.78, .78)]))
+    assert cold.status == 0 and warm.status == 0 and np.abs(cold.u - warm.u).max() < 1e-8
+    # boundary warm start (previous solution saturating accel bounds) must not cycle
+    uw = np.zeros((2, 20)); uw[0, 0] = 2.0; uw[0, 2] = -10.0
+    assert orc.qp_solve(p, st, *args, u_warm=uw).status == 0
+    st[2] = 9.0                                   # x[2,0] <= MAX_SPEED violated (mpc.py:187)
+    assert orc.qp_solve(p, st, *args).status == 2
+    p1 = orc.MpcParams(T=20, max_iter=2)
+    assert orc.qp_solve(p1, g['T20/state'][4], *args).status == 1
