@@ -164,6 +164,10 @@ int32_t mpcx_cutoff_index_batch(mpcx_ctx *ctx, int32_t P, const double *pts /*np
 int32_t mpcx_predict_obstacles_batch(mpcx_ctx *ctx, int32_t n, int32_t steps, double dt, double L,
                                      const double *obs6 /*n,6*/, double *out_xyyaw /*n,steps,3*/);
 
+/* ---- self-test of the wave-level DPP helpers the kernels rely on (scans, shifts, reductions, reciprocal):
+ * in64 = 64 doubles, out322 = results, layout documented at selftest_kernel in csrc/mpcx_misc.hip. */
+int32_t mpcx_selftest_wave_ops(mpcx_ctx *ctx, const double *in64, double *out322);
+
 /* ---- plant: lib/simulation.py:35-47 `Simulation.step` on B states with the first control of each solution;
  * failed instances (status != 0) get (previous steer, MAX_DECEL) as MPC.step does (mpc.py:294-297) and their row of
  * u is zeroed, which is the warm-start reset of mpc.py:222-224 for the next step. */

@@ -75,6 +75,58 @@ __device__ __forceinline__ double scan_down(double v, int lane) {
     return v;
 }
 
+// ---------------------------------------------------------------- DPP cross-lane helpers (no LDS round trip)
+// gfx9 DPP controls: row_shl:n 0x100+n, row_shr:n 0x110+n, wave_shl:1 0x130, wave_shr:1 0x138, row_bcast:15 0x142,
+// row_bcast:31 0x143.  A "row" is 16 consecutive lanes.  Lanes whose source is out of range keep `old`.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_mov(double old, double src) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// value of lane+1 / lane-1 (wave-wide shift by one; the edge lane gets `fill`)
+__device__ __forceinline__ double lane_next(double v, double fill = 0.0) { return dpp_mov<0x130>(fill, v); }
+__device__ __forceinline__ double lane_prev(double v, double fill = 0.0) { return dpp_mov<0x138>(fill, v); }
+
+// inclusive prefix sum over lanes 0..31 (rows 0 and 1); lanes >= 32 return garbage-free but meaningless values
+__device__ __forceinline__ double scan_up32(double v) {
+    v += dpp_mov<0x111>(0.0, v);
+    v += dpp_mov<0x112>(0.0, v);
+    v += dpp_mov<0x114>(0.0, v);
+    v += dpp_mov<0x118>(0.0, v);
+    v += dpp_mov<0x142, 0xA>(0.0, v);      // row_bcast:15 into rows 1 and 3: add the previous row's total
+    return v;
+}
+// inclusive suffix sum over lanes 0..31: lane i gets sum of lanes i..31
+__device__ __forceinline__ double scan_down32(double v, int lane) {
+    v += dpp_mov<0x101>(0.0, v);
+    v += dpp_mov<0x102>(0.0, v);
+    v += dpp_mov<0x104>(0.0, v);
+    v += dpp_mov<0x108>(0.0, v);
+    const double r1 = rdlane(v, 16);       // total of row 1
+    return v + ((lane < 16) ? r1 : 0.0);
+}
+// wave-wide reductions whose result is wave-uniform (lanes 0..63)
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_mov<0x111>(0.0, v);
+    v += dpp_mov<0x112>(0.0, v);
+    v += dpp_mov<0x114>(0.0, v);
+    v += dpp_mov<0x118>(0.0, v);           // lane 15 of each row holds the row total
+    return (rdlane(v, 15) + rdlane(v, 31)) + (rdlane(v, 47) + rdlane(v, 63));
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+    v = fmax(v, dpp_mov<0x111>(v, v));
+    v = fmax(v, dpp_mov<0x112>(v, v));
+    v = fmax(v, dpp_mov<0x114>(v, v));
+    v = fmax(v, dpp_mov<0x118>(v, v));
+    return fmax(fmax(rdlane(v, 15), rdlane(v, 31)), fmax(rdlane(v, 47), rdlane(v, 63)));
+}
+// 1/d with ONE Newton step on the hardware seed (~1e-15 relative; used where the consumer is itself iterative)
+__device__ __forceinline__ double frcp1(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+
 // lexicographic (distance, index) minimum over the wave
 __device__ __forceinline__ void wave_argmin(double &d, int &i) {
 #pragma unroll

@@ -88,7 +88,27 @@ __global__ __launch_bounds__(256) void predict_pose_kernel(PoseArgs a) {
     }
 }
 
+// self-test of the DPP wave helpers (mpcx_common.h): out[0..63] scan_up32, [64..127] scan_down32, [128..191] lane_next,
+// [192..255] lane_prev, [256] wave_sum_dpp, [257] wave_max_dpp, [258..321] frcp1(in) 
+__global__ __launch_bounds__(64) void selftest_kernel(const double *in, double *out) {
+    const int lane = threadIdx.x;
+    const double v = in[lane];
+    out[lane] = scan_up32(v);
+    out[64 + lane] = scan_down32(v, lane);
+    out[128 + lane] = lane_next(v, -1.0);
+    out[192 + lane] = lane_prev(v, -1.0);
+    const double s = wave_sum_dpp(v), m = wave_max_dpp(v);
+    if (lane == 0) { out[256] = s; out[257] = m; }
+    out[258 + lane] = frcp1(v);
+}
+
 }  // namespace mpcx
+
+extern "C" int32_t mpcx_selftest_wave_ops(mpcx_ctx *ctx, const double *in64, double *out322) {
+    if (!ctx || !in64 || !out322) return MPCX_E_INVALID;
+    hipLaunchKernelGGL(mpcx::selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, in64, out322);
+    return mpcx_check_launch(ctx, "selftest_kernel");
+}
 
 extern "C" int32_t mpcx_transform_batch(mpcx_ctx *ctx, int32_t n_items, int32_t max_pts, const double *nodes,
                                         const int32_t *pts_off, const int32_t *pts_cnt, const double *pts, double *out) {

@@ -17,6 +17,21 @@
 // registers) and two solves whose pivots travel by v_readlane.
 #include "mpcx_common.h"
 
+#ifndef MPCX_CHUNK
+#define MPCX_CHUNK 40
+#endif
+#ifndef MPCX_BCH
+#define MPCX_BCH 5
+#endif
+#ifndef MPCX_OCC
+#define MPCX_OCC 1
+#endif
+#ifdef MPCX_STAGE_BARRIER
+#define STAGE_BARRIER __builtin_amdgcn_sched_barrier(0)
+#else
+#define STAGE_BARRIER
+#endif
+
 namespace mpcx {
 
 struct QpArgs {
@@ -40,11 +55,18 @@ struct QpShared {
     double cb[2][WAVE];     // Cholesky column broadcast (double buffered)
     double ub[WAVE];        // current iterate broadcast
     double sb[WAVE];        // speed-row suffix sums broadcast
+    double dump[WAVE];      // write target of lanes that have no band entry to patch
 };
 
 // All hot loops below are written branch-free (selects / 0-1 masks): a single straight-line block keeps the
 // register allocator out of scratch.  The block is ONE wavefront, so LDS traffic between lanes is ordered by
 // the in-order LDS queue; `lds_sync()` only stops the compiler from reordering across it.
+// compiler-only ordering point between LDS accesses of different lanes (no scheduling barrier)
+__device__ __forceinline__ void lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -56,25 +78,25 @@ __device__ __forceinline__ void lds_sync() {
 // updates of the unrolled loops below their last use and spills every operand to scratch.
 __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
 
-// forward/backward substitution with the factor held as: lane i, R[k] = L(i,k) for k<i, 0 for k==i and, for
-// k>i, the UNSCALED Schur-complement entry M_i(i,k) = L(k,i)*L(i,i) the lane held when its column was
-// eliminated; invd = 1/L(i,i).  (Scaling that transposed part in place would need a per-element select or
-// lose sqrt(pivot) digits to cancellation; the backward sweep applies invd once per lane instead.)
+// Solve (L~ D L~') x = b with the factor held as: lane i, R[k] = L~(i,k) (unit lower factor) for k<i, 0 for k==i and,
+// for k>i, the UNSCALED Schur-complement entry M_i(i,k) = L~(k,i)*d_i the lane held when its column was eliminated;
+// dinv = 1/d_i.  (Scaling the transposed part in place would cost a select per element or lose digits to
+// cancellation; the backward sweep applies dinv once per lane instead.)  Pivots travel by v_readlane.
 template <int N>
-__device__ __forceinline__ double chol_solve(const double (&R)[N], double invd, double b, int lane) {
-    double acc = b, y = 0.0;
+__device__ __forceinline__ double ldl_solve(const double (&R)[N], double dinv, double b, int lane) {
+    double acc = b, z = 0.0;
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        double tmp = acc * invd;
-        double yj = rdlane(tmp, j);
-        y = (lane == j) ? tmp : y;
-        acc = fma(-R[j], yj, acc);
+        const double zj = rdlane(acc, j);
+        z = (lane == j) ? acc : z;
+        acc = fma(-R[j], zj, acc);
     }
+    const double w = z * dinv;
     double sum = 0.0, x = 0.0;
 #pragma unroll
     for (int j = N - 1; j >= 0; j--) {
-        double tmp = fma(-invd, sum, y) * invd;
-        double xj = rdlane(tmp, j);
+        const double tmp = fma(-dinv, sum, w);
+        const double xj = rdlane(tmp, j);
         x = (lane == j) ? tmp : x;
         sum = fma(R[j], xj, sum);
     }
@@ -82,8 +104,11 @@ __device__ __forceinline__ double chol_solve(const double (&R)[N], double invd, 
 }
 
 template <int NT>
-__global__ __launch_bounds__(64, 2) void qp_kernel(QpArgs a) {
+__global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     constexpr int N = 2 * NT;
+    constexpr int CHUNK = MPCX_CHUNK;      // LDS values staged per batch in the unrolled loops
+    constexpr int PRE = (N - 1 < 12) ? N - 1 : 12;   // column entries prefetched one column ahead in the factorisation
+    constexpr int BCH = MPCX_BCH;          // same, stage pairs in the Hessian build (8 doubles each)
     __shared__ QpShared<NT> sh;
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -179,11 +204,24 @@ __global__ __launch_bounds__(64, 2) void qp_kernel(QpArgs a) {
             g += gx * sh.we[t][0] + gy * sh.we[t][1] + gv * sh.we[t][2] + gp * sh.we[t][3];
             lds_sync();
             // only unknowns of stages < t have a non-zero sensitivity at time t
+            {
 #pragma unroll
-            for (int kk = 0; kk < t; kk++) {
-                R[kk] += gx * sh.gb[kk][0] + gy * sh.gb[kk][1] + gv * sh.gb[kk][2] + gp * sh.gb[kk][3];
-                R[NT + kk] += gx * sh.gb[NT + kk][0] + gy * sh.gb[NT + kk][1] + gv * sh.gb[NT + kk][2] + gp * sh.gb[NT + kk][3];
-                pin(R[kk]); pin(R[NT + kk]);
+                for (int k0 = 0; k0 < t; k0 += BCH) {
+                    const int k1 = (k0 + BCH < t) ? k0 + BCH : t;
+                    double w4[2 * NT][4];
+#pragma unroll
+                    for (int kk = k0; kk < k1; kk++) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) { w4[kk][c] = sh.gb[kk][c]; w4[NT + kk][c] = sh.gb[NT + kk][c]; }
+                    }
+#pragma unroll
+                    for (int kk = k0; kk < k1; kk++) {
+                        R[kk] += gx * w4[kk][0] + gy * w4[kk][1] + gv * w4[kk][2] + gp * w4[kk][3];
+                        R[NT + kk] += gx * w4[NT + kk][0] + gy * w4[NT + kk][1] + gv * w4[NT + kk][2] + gp * w4[NT + kk][3];
+                    }
+#pragma unroll
+                    for (int kk = k0; kk < k1; kk++) { pin(R[kk]); pin(R[NT + kk]); }
+                }
             }
             lds_sync();
         }
@@ -208,6 +246,14 @@ __global__ __launch_bounds__(64, 2) void qp_kernel(QpArgs a) {
             for (int j = 0; j < N; j++) sh.H[j * N + lane] = R[j];
         }
     }
+    lds_sync();
+    // pristine band entries H(i,i), H(i,i+1), H(i,i-1) of this lane's row: each iteration writes "band + G'DG band"
+    // into LDS so that the row can be read back without per-element selects
+    const bool has_hi = lane + 1 < N, has_lo = inrow && lane >= 1;
+    double *const p_d = inrow ? &sh.H[lane * N + lane] : &sh.dump[lane];
+    double *const p_hi = has_hi ? &sh.H[(lane + 1) * N + lane] : &sh.dump[lane];
+    double *const p_lo = has_lo ? &sh.H[(lane - 1) * N + lane] : &sh.dump[lane];
+    const double h_d = *p_d, h_hi = has_hi ? *p_hi : 0.0, h_lo = has_lo ? *p_lo : 0.0;
 
     // ---------------------------------------------------------------- constraints owned by this lane
     // rows 0/1: +-u_i box ; rows 2/3: accel lane k -> +-v_{k+1} speed rows, steer lane k -> +-(d_{k+1}-d_k)
@@ -225,17 +271,17 @@ __global__ __launch_bounds__(64, 2) void qp_kernel(QpArgs a) {
     double u = 0.0;
     if (real && a.u_warm) u = a.u_warm[(size_t)b * 2 * T + kind * T + k];
 
-    // (G x) of the second row pair: accel lane: dt * sum_{j<=k} a_j ; steer lane: d_{k+1} - d_k
+    // (G x) of the second row pair: accel lane: dt * sum_{j<=k} a_j ; steer lane: d_{k+1} - d_k   (DPP, no LDS)
     auto second_rows = [&](double x) -> double {
-        const double pa = scan_up(ma * x, lane);
-        const double nx = __shfl_down(x, 1, WAVE);
+        const double pa = scan_up32(ma * x);
+        const double nx = lane_next(x);
         return m23 * (kind == 0 ? dt * pa : (nx - x));
     };
     // (G' w) for this unknown from the lane's w0..w3 (already masked)
     auto gt_apply = [&](double w0, double w1, double w2, double w3) -> double {
         const double q = w2 - w3;
-        const double sa = scan_down(ma * q, lane);             // sum_{j>=k} q_j over accel lanes
-        const double qp = k0m * __shfl_up(q, 1, WAVE);         // q_{k-1}
+        const double sa = scan_down32(ma * q, lane);            // sum_{j>=k} q_j over accel lanes
+        const double qp = k0m * lane_prev(q);                   // q_{k-1}
         return (w0 - w1) + (kind == 0 ? dt * sa : (qp - q));
     };
 
@@ -244,106 +290,147 @@ __global__ __launch_bounds__(64, 2) void qp_kernel(QpArgs a) {
         const double e2 = second_rows(u);
         s0 = fmax(h0 - u, 0.5); s1 = fmax(h1 + u, 0.5); s2 = fmax(h2 - e2, 0.5); s3 = fmax(h3 + e2, 0.5);
     }
-    const double gnorm = fmax(1.0, wave_max(real ? fabs(g) : 0.0));
-    const double hnorm = fmax(1.0, wave_max(fmax(m01 * fmax(fabs(h0), fabs(h1)), m23 * fmax(fabs(h2), fabs(h3)))));
+    const double gnorm = fmax(1.0, wave_max_dpp(real ? fabs(g) : 0.0));
+    const double hnorm = fmax(1.0, wave_max_dpp(fmax(m01 * fmax(fabs(h0), fabs(h1)), m23 * fmax(fabs(h2), fabs(h3)))));
+    const double ign = 1.0 / gnorm, ihn = 1.0 / hnorm;
 
     int status = MPCX_QP_MAXITER;
     int it = 0;
-    double res_d = 0, res_p = 0, mu = 0;
+    double mu = 0, rd = 0, rp0 = 0, rp1 = 0, rp2 = 0, rp3 = 0;
     const double dt2 = dt * dt;
     const double tol_loose = P.tol > 1e-7 ? P.tol : 1e-7;
     // x[2,0] rows of mpc.py:187-188 are constants: outside the speed interval the problem is infeasible
     const bool feasible0 = !(v0 > P.max_speed + 1e-9 || v0 < P.min_speed - 1e-9);
     if (!feasible0) status = MPCX_QP_INFEASIBLE;
     const int max_iter = feasible0 ? P.max_iter : -1;
+    const double rowm = inrow ? 1.0 : 0.0;
 
     for (it = 0; it <= max_iter; it++) {
-        // -------- residuals
+        // -------- H u from the PRISTINE Hessian (restore the band entries the previous iteration patched)
+        *p_d = h_d; *p_hi = h_hi; *p_lo = h_lo;
         sh.ub[lane] = u;
         lds_sync();
         double hu = 0.0;
-        const double rowm = inrow ? 1.0 : 0.0;
 #pragma unroll
-        for (int j = 0; j < N; j++) {
-            R[j] = rowm * sh.H[j * N + li];
-            hu = fma(R[j], sh.ub[j], hu);
-        }
+        for (int j = 0; j < N; j++) hu = fma(sh.H[j * N + li], sh.ub[j], hu);
+        // -------- residuals
         const double e2 = second_rows(u);
-        const double rd = m01 * (hu + g + gt_apply(m01 * l0, m01 * l1, m23 * l2, m23 * l3));
-        const double rp0 = m01 * (u + s0 - h0), rp1 = m01 * (-u + s1 - h1);
-        const double rp2 = m23 * (e2 + s2 - h2), rp3 = m23 * (-e2 + s3 - h3);
-        mu = wave_sum(m01 * (s0 * l0 + s1 * l1) + m23 * (s2 * l2 + s3 * l3)) * minv;
-        res_d = wave_max(fabs(rd));
-        res_p = wave_max(fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))));
+        rd = m01 * (hu + g + gt_apply(m01 * l0, m01 * l1, m23 * l2, m23 * l3));
+        rp0 = m01 * (u + s0 - h0); rp1 = m01 * (-u + s1 - h1);
+        rp2 = m23 * (e2 + s2 - h2); rp3 = m23 * (-e2 + s3 - h3);
+        mu = wave_sum_dpp(m01 * (s0 * l0 + s1 * l1) + m23 * (s2 * l2 + s3 * l3)) * minv;
+        const double resn = wave_max_dpp(fmax(fabs(rd) * ign, fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))) * ihn));
 #ifdef MPCX_QP_TRACE
-        if (b == MPCX_QP_TRACE && lane == 0) printf("it %d res_d %.3e res_p %.3e mu %.3e gnorm %.3e hnorm %.3e\n", it, res_d, res_p, mu, gnorm, hnorm);
+        if (b == MPCX_QP_TRACE && lane == 0) printf("it %d resn %.3e mu %.3e gnorm %.3e hnorm %.3e\n", it, resn, mu, gnorm, hnorm);
 #endif
-        if (res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol) { status = MPCX_QP_OPTIMAL; break; }
+#ifdef MPCX_FIXED_ITERS
+        if (it == MPCX_FIXED_ITERS) { status = MPCX_QP_OPTIMAL; break; }
+#else
+        if (resn <= P.tol && mu <= P.tol) { status = MPCX_QP_OPTIMAL; break; }
+#endif
         // reduced-accuracy acceptance when the iteration cannot continue (the reference accepts ECOS's OPTIMAL_INACCURATE, mpc.py:196)
-        const bool loose = res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose;
+        const bool loose = resn <= tol_loose && mu <= tol_loose;
         if (it == max_iter) { if (loose) status = MPCX_QP_OPTIMAL; break; }
 
-        // -------- M = H + G' D G  (row `lane` in R[])
-        const double is0 = frcp(s0), is1 = frcp(s1), is2 = frcp(s2), is3 = frcp(s3);
+        // -------- row of M = H + G'DG: the band part (diagonal + steer tridiagonal) is written into LDS so that the row
+        // reads back without per-element selects; the accel block adds dt^2 * min(S_i, S_j)
+        const double is0 = frcp1(s0), is1 = frcp1(s1), is2 = frcp1(s2), is3 = frcp1(s3);
         const double d0 = m01 * l0 * is0, d1 = m01 * l1 * is1, d2 = m23 * l2 * is2, d3 = m23 * l3 * is3;
         const double r23 = d2 + d3;
-        const double S = scan_down(ma * r23, lane);      // accel lanes: sum_{j>=k} (d2+d3)_j ; elsewhere 0
-        sh.sb[lane] = S;
-        lds_sync();
+        const double S = scan_down32(ma * r23, lane);    // accel lanes: sum_{j>=k} (d2+d3)_j ; elsewhere 0
         const double r_own = kind ? r23 : 0.0;
-        const double r_prev = k0m * __shfl_up(r_own, 1, WAVE);
-        const double dgm = d0 + d1 + r_own + r_prev;
+        const double r_prev = k0m * lane_prev(r_own);
+        sh.sb[lane] = S;
+        *p_d = h_d + (d0 + d1 + r_own + r_prev);
+        *p_hi = h_hi - r_own;
+        *p_lo = h_lo - r_prev;
+        lds_sync();
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            if (j < NT) R[j] = fma(dt2, fmin(S, sh.sb[j]), R[j]);
-            double add = (lane == j) ? dgm : 0.0;
-            add = (lane == j - 1) ? -r_own : add;
-            add = (lane == j + 1) ? -r_prev : add;
-            R[j] += add;
+            double v = rowm * sh.H[j * N + li];
+            if (j < NT) v = fma(dt2, fmin(S, sh.sb[j]), v);
+            R[j] = v;
         }
 
-        // -------- Cholesky (right-looking; see file header)
-        double invd = 1.0;
+        // -------- M = L~ D L~' (right-looking; see file header)
+        // Software pipeline per column j (one straight-line region each):
+        //  * the pivots form the only serial chain: d_{j+1} = M_j(j+1,j+1) - M_j(j+1,j)^2 / d_j uses lane j+1's OWN two
+        //    entries (v_readlane), so 1/d_{j+1} is computed while column j's trailing update issues;
+        //  * column j+1 is published to LDS right after its first update and its first PRE entries are read back
+        //    immediately, so the next column starts without an exposed LDS round trip.
+        double dinv = 1.0;
         bool bad = false;
+        double pre[2][PRE];
         sh.cb[0][lane] = R[0];
-        lds_sync();
+        lds_order();
+#pragma unroll
+        for (int q = 0; q < PRE; q++) pre[0][q] = (1 + q < N) ? sh.cb[0][1 + q] : 0.0;
+        double rinv;
+        {
+            const double d0 = rdlane(R[0], 0);
+            bad = !(d0 > 0.0);
+            rinv = frcp(bad ? 1.0 : d0);
+        }
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            const double *col = sh.cb[j & 1];
-            double d = col[j];
-            bad = bad || !(d > 0.0);
-            d = (d > 0.0) ? d : 1.0;
-            const double rinv = frcp(d), rs = frsq(d);
-            const double tj = (lane > j) ? R[j] * rinv : 0.0;
+            constexpr int dummy = 0; (void)dummy;
+            const int p = j & 1;
+            const double *col = sh.cb[p];
+            const double tj = (lane > j) ? R[j] * rinv : 0.0;          // L~(lane, j)
+            double rinv_n = 1.0;
             if (j + 1 < N) {
-                R[j + 1] = fma(-tj, col[j + 1], R[j + 1]);
-                sh.cb[(j + 1) & 1][lane] = R[j + 1];
-            }
+                const double a1 = rdlane(R[j], j + 1), d1 = rdlane(R[j + 1], j + 1);
+                const double dn = fma(-(a1 * rinv), a1, d1);            // next pivot (wave-uniform)
+                bad = bad || !(dn > 0.0);
+                rinv_n = frcp((dn > 0.0) ? dn : 1.0);                  // full accuracy: errors here are amplified by cond(M)
+                R[j + 1] = fma(-tj, pre[p][0], R[j + 1]);
+                sh.cb[p ^ 1][lane] = R[j + 1];
+                lds_order();
 #pragma unroll
-            for (int kk = j + 2; kk < N; kk++) { R[kk] = fma(-tj, col[kk], R[kk]); pin(R[kk]); }
-            R[j] = (lane > j) ? R[j] * rs : ((lane == j) ? 0.0 : R[j]);
-            invd = (lane == j) ? rs : invd;
-            lds_sync();
+                for (int q = 0; q < PRE; q++) pre[p ^ 1][q] = (j + 2 + q < N) ? sh.cb[p ^ 1][j + 2 + q] : 0.0;
+            }
+#ifndef MPCX_SKIP_TRAIL
+            {
+                // loads first, then FMAs, then the (volatile) pins: a pin between two loads would serialise them
+                double cv[N];
+#pragma unroll
+                for (int kk = j + 2; kk < N; kk++) cv[kk] = (kk - (j + 1) < PRE) ? pre[p][kk - (j + 1)] : col[kk];
+#pragma unroll
+                for (int kk = j + 2; kk < N; kk++) R[kk] = fma(-tj, cv[kk], R[kk]);
+#pragma unroll
+                for (int kk = j + 2; kk < N; kk++) pin(R[kk]);
+            }
+#endif
+            R[j] = (lane < j) ? R[j] : tj;                              // lanes < j keep their unscaled Schur entry, lane j gets 0
+            dinv = (lane == j) ? rinv : dinv;
+            rinv = rinv_n;
+            __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef MPCX_FIXED_ITERS
         if (bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; break; }
+#endif
 
         // -------- predictor (affine scaling) direction
         double w0 = -m01 * l0 + d0 * rp0, w1 = -m01 * l1 + d1 * rp1, w2 = -m23 * l2 + d2 * rp2, w3 = -m23 * l3 + d3 * rp3;
         double rhs = m01 * (-rd - gt_apply(w0, w1, w2, w3));
-        double du = m01 * chol_solve<N>(R, invd, rhs, lane);
+#ifdef MPCX_SKIP_SOLVE
+        double du = m01 * rhs * dinv;
+#else
+        double du = m01 * ldl_solve<N>(R, dinv, rhs, lane);
+#endif
         double f2 = second_rows(du);
         const double dsa0 = -rp0 - m01 * du, dsa1 = -rp1 + m01 * du, dsa2 = -rp2 - f2, dsa3 = -rp3 + f2;
         const double dla0 = m01 * (-l0 - d0 * dsa0), dla1 = m01 * (-l1 - d1 * dsa1);
         const double dla2 = m23 * (-l2 - d2 * dsa2), dla3 = m23 * (-l3 - d3 * dsa3);
-        const double il0 = frcp(l0), il1 = frcp(l1), il2 = frcp(l2), il3 = frcp(l3);
+        const double il0 = frcp1(l0), il1 = frcp1(l1), il2 = frcp1(l2), il3 = frcp1(l3);
         // largest step keeping s, lam >= 0: 1 / max(-ds/s, -dlam/lam)
         double rat = fmax(fmax(-dsa0 * is0, -dla0 * il0), fmax(-dsa1 * is1, -dla1 * il1));
         rat = fmax(rat, fmax(fmax(-dsa2 * is2, -dla2 * il2), fmax(-dsa3 * is3, -dla3 * il3)));
-        rat = wave_max(rat);
+        rat = wave_max_dpp(rat);
         const double al = (rat > 1.0) ? frcp(rat) : 1.0;
         double mu_aff = m01 * ((s0 + al * dsa0) * (l0 + al * dla0) + (s1 + al * dsa1) * (l1 + al * dla1)) +
                         m23 * ((s2 + al * dsa2) * (l2 + al * dla2) + (s3 + al * dsa3) * (l3 + al * dla3));
-        mu_aff = wave_sum(mu_aff) * minv;
+        mu_aff = wave_sum_dpp(mu_aff) * minv;
         double sigma = mu_aff * frcp(mu);
         sigma = sigma * sigma * sigma;
         const double smu = sigma * mu;
@@ -355,19 +442,26 @@ __global__ __launch_bounds__(64, 2) void qp_kernel(QpArgs a) {
         w0 = m01 * (-rc0 + l0 * rp0) * is0; w1 = m01 * (-rc1 + l1 * rp1) * is1;
         w2 = m23 * (-rc2 + l2 * rp2) * is2; w3 = m23 * (-rc3 + l3 * rp3) * is3;
         rhs = m01 * (-rd - gt_apply(w0, w1, w2, w3));
-        du = m01 * chol_solve<N>(R, invd, rhs, lane);
+#ifdef MPCX_SKIP_SOLVE
+        du = m01 * rhs * dinv;
+#else
+        du = m01 * ldl_solve<N>(R, dinv, rhs, lane);
+#endif
         f2 = second_rows(du);
         const double ds0 = -rp0 - m01 * du, ds1 = -rp1 + m01 * du, ds2 = -rp2 - f2, ds3 = -rp3 + f2;
         const double dl0 = -m01 * (rc0 + l0 * ds0) * is0, dl1 = -m01 * (rc1 + l1 * ds1) * is1;
         const double dl2 = -m23 * (rc2 + l2 * ds2) * is2, dl3 = -m23 * (rc3 + l3 * ds3) * is3;
         rat = fmax(fmax(-ds0 * is0, -dl0 * il0), fmax(-ds1 * is1, -dl1 * il1));
         rat = fmax(rat, fmax(fmax(-ds2 * is2, -dl2 * il2), fmax(-ds3 * is3, -dl3 * il3)));
-        rat = wave_max(rat);
+        rat = wave_max_dpp(rat);
         const double alpha = (0.995 < rat) ? 0.995 * frcp(rat) : 1.0;     // min(1, 0.995/rat)
         u += alpha * du;
         s0 += alpha * ds0; s1 += alpha * ds1; s2 += alpha * ds2; s3 += alpha * ds3;
         l0 += alpha * dl0; l1 += alpha * dl1; l2 += alpha * dl2; l3 += alpha * dl3;
     }
+    // exit residuals (absolute, for the kkt[] report)
+    const double res_d = wave_max_dpp(fabs(rd));
+    const double res_p = wave_max_dpp(fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))));
 
     // ---------------------------------------------------------------- outputs: u and the linear prediction x
     if (real) a.u_out[(size_t)b * 2 * T + kind * T + k] = u;
@@ -379,12 +473,12 @@ __global__ __launch_bounds__(64, 2) void qp_kernel(QpArgs a) {
         const int sc = on ? s : 0;
         const double onm = on ? 1.0 : 0.0;
         const double as = onm * sh.ub[sc], dsb = onm * sh.ub[NT + sc] * sh.beta[sc];
-        const double va = scan_up(as, lane), fd = scan_up(dsb, lane);
+        const double va = scan_up32(as), fd = scan_up32(dsb);
         const double vs = dt * (va - as), ps = fd - dsb;       // deviation of (v, yaw) at stage s from (v0, yaw0)
         const double p0 = sh.pre[0][sc + 1] - sh.pre[0][sc], p1 = sh.pre[1][sc + 1] - sh.pre[1][sc];
         const double q0 = sh.pre[2][sc + 1] - sh.pre[2][sc], q1 = sh.pre[3][sc + 1] - sh.pre[3][sc];
         const double ix = onm * (p0 * vs + q0 * ps), iy = onm * (p1 * vs + q1 * ps);
-        const double X = scan_up(ix, lane), Y = scan_up(iy, lane);
+        const double X = scan_up32(ix), Y = scan_up32(iy);
         double *xo = a.x_out + (size_t)b * 4 * W;
         if (on) {
             const int t = s + 1;

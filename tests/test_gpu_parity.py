@@ -136,3 +136,21 @@ def test_interaction_vs_golden(ctx):
     m = hit >= 0
     assert np.array_equal(xy[m], gh[m, :2])
     assert np.array_equal(tidx.cpu().numpy(), idx)
+
+
+def test_wave_helpers_selftest(ctx):
+    """DPP scans / shifts / reductions used inside qp_kernel"""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    v = rng.uniform(0.5, 3.0, 64) * rng.choice([-1.0, 1.0], 64)
+    inp = ctx.f64(v); out = torch.zeros(322, dtype=torch.float64, device=ctx.device)
+    rc = ctx.lib.mpcx_selftest_wave_ops(ctx._ctx, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()))
+    assert rc == 0
+    ctx.synchronize()
+    o = out.cpu().numpy()
+    assert np.abs(o[:32] - np.cumsum(v[:32])).max() < 1e-13
+    assert np.abs(o[64:96] - np.cumsum(v[:32][::-1])[::-1]).max() < 1e-13
+    assert np.array_equal(o[128:191], v[1:]) and o[191] == -1.0
+    assert np.array_equal(o[193:256], v[:-1]) and o[192] == -1.0
+    assert abs(o[256] - v.sum()) < 1e-12 and o[257] == v.max()
+    assert np.abs(o[258:] * v - 1.0).max() < 1e-14
