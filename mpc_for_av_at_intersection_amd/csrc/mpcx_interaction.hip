@@ -78,9 +78,10 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // collision_avoidance.py:72-104 on prepared disc tables.  s_ego: ego disc centres of the `na` predicted poses;
 // pred: obstacle disc centres [pool][steps][2][2]; (rem, rcs, n): the detailed path and cos/sin of its yaw.
 // Returns the index of the earliest conflicting pose on the detailed path (and its x,y) or -1 (None).
+constexpr int NSEG = 8;
 __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)[4], int na, const double *pred,
                               int ooff, int nobs, int oskip, const double *rem, const double *rcs, int n,
-                              int *s_cand, int lane, double &hx, double &hy) {
+                              int *s_cand, double (*s_box)[4], int lane, double &hx, double &hy) {
     const double md = 2.0 * ip.radius;
     const int steps = ip.pred_steps, w = ip.frame_window;
     double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
@@ -116,30 +117,50 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
     const int ncand = cbase;
     __syncthreads();
 
-    // ---- exact test of survivors; key = reference row order (frame, agent disc, obstacle, offset, obstacle disc)
+    // ---- exact test of survivors; key = reference row order (frame, agent disc, obstacle, offset, obstacle disc).
+    // Second, finer exact cull: the F frames are cut into NSEG runs, each with the bounding box of its ego discs; a survivor
+    // is only compared with the frames of runs whose (inflated) box contains it.
     const int F = na > steps ? na : steps;
+    const int SL = (F + NSEG - 1) / NSEG;                 // frames per run
+    if (lane < NSEG) {
+        double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+        for (int f = lane * SL; f < (lane + 1) * SL && f < F; f++) {
+            const int fe = f < na ? f : na - 1;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const double ex = s_ego[fe][2 * d], ey = s_ego[fe][2 * d + 1];
+                x0 = fmin(x0, ex); x1 = fmax(x1, ex); y0 = fmin(y0, ey); y1 = fmax(y1, ey);
+            }
+        }
+        s_box[lane][0] = x0 - slack; s_box[lane][1] = x1 + slack; s_box[lane][2] = y0 - slack; s_box[lane][3] = y1 + slack;
+    }
+    __syncthreads();
     const long long NOKEY = 0x7fffffffffffffffLL;
     long long best = NOKEY;
-    const long long npairs = (long long)ncand * F;
-    for (long long q0 = 0; q0 < npairs; q0 += WAVE) {
-        const long long qi = q0 + lane;
+    const int npairs = ncand * NSEG;
+    for (int q0 = 0; q0 < npairs; q0 += WAVE) {
+        const int qi = q0 + lane;
         if (qi < npairs) {
-            const int ci = (int)(qi / F), f = (int)(qi % F);
+            const int ci = qi / NSEG, sg = qi % NSEG;
             const int cidx = s_cand[ci];
             const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;
-            const int ff = f < steps ? f : steps - 1;
-            if (abs(g - ff) <= w) {      // some offset d in [-w, w] maps padded frame ff onto obstacle frame g
-                int pool = ooff + o;
-                if (oskip >= 0 && pool >= oskip) pool += 1;
-                const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
-                const double ox = qq[0], oy = qq[1];
-                const int fe = f < na ? f : na - 1;
+            int pool = ooff + o;
+            if (oskip >= 0 && pool >= oskip) pool += 1;
+            const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
+            const double ox = qq[0], oy = qq[1];
+            if (ox >= s_box[sg][0] && ox <= s_box[sg][1] && oy >= s_box[sg][2] && oy <= s_box[sg][3]) {
+                const int f1 = (sg + 1) * SL < F ? (sg + 1) * SL : F;
+                for (int f = sg * SL; f < f1; f++) {
+                    const int ff = f < steps ? f : steps - 1;
+                    if (abs(g - ff) > w) continue;       // no offset d in [-w, w] maps padded frame ff onto obstacle frame g
+                    const int fe = f < na ? f : na - 1;
 #pragma unroll
-                for (int ca = 0; ca < 2; ca++) {
-                    if (dist2d(s_ego[fe][2 * ca], s_ego[fe][2 * ca + 1], ox, oy) <= md) {
-                        // offsets ascend => obstacle frames descend; the first offset reaching g is the one that counts
-                        const long long key = ((((long long)f * 2 + ca) * MPCX_MAX_OBS + o) * MPCX_PRED_STEPS_MAX + (steps - 1 - g)) * 2 + co;
-                        best = key < best ? key : best;
+                    for (int ca = 0; ca < 2; ca++) {
+                        if (dist2d(s_ego[fe][2 * ca], s_ego[fe][2 * ca + 1], ox, oy) <= md) {
+                            // offsets ascend => obstacle frames descend; the first offset reaching g is the one that counts
+                            const long long key = ((((long long)f * 2 + ca) * MPCX_MAX_OBS + o) * MPCX_PRED_STEPS_MAX + (steps - 1 - g)) * 2 + co;
+                            best = key < best ? key : best;
+                        }
                     }
                 }
             }
@@ -182,6 +203,7 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     __shared__ int s_keep[MAXF];
     __shared__ double s_ego[MAXF][4];     // ego disc centres per kept pose: (x0,y0,x1,y1)
     __shared__ int s_cand[MAXCAND];       // surviving obstacle disc ids: (o*steps + g)*2 + co
+    __shared__ double s_box[NSEG][4];     // bounding boxes of the ego discs per run of frames
 
     const int p = blockIdx.x, lane = threadIdx.x;
     const mpcx_interaction_params &ip = a.ip;
@@ -220,9 +242,19 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     for (int i = lane; i < n; i += WAVE)
         s_cum[i] = (i == 0) ? 0.0 : dist2d(rem[3 * i], rem[3 * i + 1], rem[3 * (i - 1)], rem[3 * (i - 1) + 1]);
     __syncthreads();
-    if (lane == 0) {                      // np.cumsum: strictly sequential adds
+    if (lane == 0) {                      // np.cumsum: strictly sequential adds (one lane; loads batched 16 at a time)
         double c = 0.0;
-        for (int i = 0; i < n; i++) { c = __dadd_rn(c, s_cum[i]); s_cum[i] = c; }
+        int i = 0;
+        for (; i + 16 <= n; i += 16) {
+            double t[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) t[q] = s_cum[i + q];
+#pragma unroll
+            for (int q = 0; q < 16; q++) { c = __dadd_rn(c, t[q]); t[q] = c; }
+#pragma unroll
+            for (int q = 0; q < 16; q++) s_cum[i + q] = t[q];
+        }
+        for (; i < n; i++) { c = __dadd_rn(c, s_cum[i]); s_cum[i] = c; }
     }
     __syncthreads();
     const bool accel_phase = v < ip.max_speed;
@@ -269,7 +301,7 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     __syncthreads();
     const int ooff = a.obs_off[p], oskip = a.obs_skip ? a.obs_skip[p] : -1;
     double hx, hy;
-    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_cand, lane, hx, hy);
+    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_cand, s_box, lane, hx, hy);
     if (first < 0) {
         if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
@@ -321,6 +353,7 @@ struct MovArgs {
 __global__ __launch_bounds__(64) void moving_collision_kernel(MovArgs a) {
     __shared__ double s_ego[MAXF][4];
     __shared__ int s_cand[MAXCAND];
+    __shared__ double s_box[NSEG][4];
     const int p = blockIdx.x, lane = threadIdx.x;
     const mpcx_interaction_params &ip = a.ip;
     const int na = a.ego_len[p], n = a.path_len[p], nobs = a.obs_cnt[p];
@@ -339,7 +372,7 @@ __global__ __launch_bounds__(64) void moving_collision_kernel(MovArgs a) {
     __syncthreads();
     double hx, hy;
     const int first = first_conflict(ip, s_ego, na, a.pred, a.obs_off[p], nobs, -1,
-                                     a.path + 3 * (size_t)a.path_off[p], a.path_cs + 2 * (size_t)a.path_off[p], n, s_cand, lane, hx, hy);
+                                     a.path + 3 * (size_t)a.path_off[p], a.path_cs + 2 * (size_t)a.path_off[p], n, s_cand, s_box, lane, hx, hy);
     if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = first < 0 ? 0.0 : hx; a.hit_xy[2 * p + 1] = first < 0 ? 0.0 : hy; }
 }
 

@@ -20,6 +20,9 @@
 #ifndef MPCX_CHUNK
 #define MPCX_CHUNK 40
 #endif
+#ifndef MPCX_PRE
+#define MPCX_PRE 8
+#endif
 #ifndef MPCX_BCH
 #define MPCX_BCH 5
 #endif
@@ -37,6 +40,8 @@ namespace mpcx {
 struct QpArgs {
     mpcx_mpc_params p;
     int B;
+    int has_warm;         // u_warm != NULL (tested on the host: a device-side null test of a kernel-argument pointer trips a
+                          // gfx950 instruction-selection bug in some register-allocation outcomes)
     const double *x0, *xref, *xbar, *u_warm;
     const uint8_t *re;
     double *x_out, *u_out, *kkt;
@@ -46,7 +51,8 @@ struct QpArgs {
 template <int NT>
 struct QpShared {
     static constexpr int N = 2 * NT;
-    double H[N * N];        // column-major: H[k*N + i] = H(i,k); lane i reads/writes its own row conflict-free
+    double H[N * N + WAVE]; // column-major: H[k*N + i] = H(i,k); lane i reads/writes its own row conflict-free;
+                            // the last WAVE slots are a write sink for lanes that have no band entry to patch
     double pre[6][NT + 1];  // exclusive prefix sums over t: Px, Py (accel paths), Qx, Qy (steer paths), Cx, Cy (affine)
     double beta[32];        // dt * vbar_k / L
     double wt[33][6];       // per-t cost weights: wxx, wxy, wyy, wv, wyaw
@@ -55,7 +61,6 @@ struct QpShared {
     double cb[2][WAVE];     // Cholesky column broadcast (double buffered)
     double ub[WAVE];        // current iterate broadcast
     double sb[WAVE];        // speed-row suffix sums broadcast
-    double dump[WAVE];      // write target of lanes that have no band entry to patch
 };
 
 // All hot loops below are written branch-free (selects / 0-1 masks): a single straight-line block keeps the
@@ -78,36 +83,28 @@ __device__ __forceinline__ void lds_sync() {
 // updates of the unrolled loops below their last use and spills every operand to scratch.
 __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
 
-// Solve (L~ D L~') x = b with the factor held as: lane i, R[k] = L~(i,k) (unit lower factor) for k<i, 0 for k==i and,
-// for k>i, the UNSCALED Schur-complement entry M_i(i,k) = L~(k,i)*d_i the lane held when its column was eliminated;
-// dinv = 1/d_i.  (Scaling the transposed part in place would cost a select per element or lose digits to
-// cancellation; the backward sweep applies dinv once per lane instead.)  Pivots travel by v_readlane.
+// Solve (L~ D L~') x = b.  Lane i holds Rlo[k] = L~(i,k) for k<i (0 for k>=i) and Rup[k] = the UNSCALED Schur-complement
+// entry M_i(i,k) = L~(k,i)*d_i for k>i (0 for k<=i) -- the row the lane held when its own column was eliminated -- and
+// dinv = 1/d_i.  With the zero fills neither sweep can disturb a finished lane, so no per-step capture is needed; scaling
+// the transposed part in place would cost a select per element or lose digits, the backward sweep applies dinv instead.
+// Pivots travel by v_readlane.
 template <int N>
-__device__ __forceinline__ double ldl_solve(const double (&R)[N], double dinv, double b, int lane) {
-    double acc = b, z = 0.0;
+__device__ __forceinline__ double ldl_solve(const double (&Rlo)[N], const double (&Rup)[N], double dinv, double b, int lane) {
+    double acc = b;
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-        const double zj = rdlane(acc, j);
-        z = (lane == j) ? acc : z;
-        acc = fma(-R[j], zj, acc);
-    }
-    const double w = z * dinv;
-    double sum = 0.0, x = 0.0;
+    for (int j = 0; j < N; j++) acc = fma(-Rlo[j], rdlane(acc, j), acc);
+    const double w = acc * dinv;
+    double sum = 0.0;
 #pragma unroll
-    for (int j = N - 1; j >= 0; j--) {
-        const double tmp = fma(-dinv, sum, w);
-        const double xj = rdlane(tmp, j);
-        x = (lane == j) ? tmp : x;
-        sum = fma(R[j], xj, sum);
-    }
-    return x;
+    for (int j = N - 1; j >= 0; j--) sum = fma(Rup[j], rdlane(fma(-dinv, sum, w), j), sum);
+    return fma(-dinv, sum, w);
 }
 
 template <int NT>
 __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     constexpr int N = 2 * NT;
     constexpr int CHUNK = MPCX_CHUNK;      // LDS values staged per batch in the unrolled loops
-    constexpr int PRE = (N - 1 < 12) ? N - 1 : 12;   // column entries prefetched one column ahead in the factorisation
+    constexpr int PRE = (N - 1 < MPCX_PRE) ? N - 1 : MPCX_PRE;   // column entries prefetched one column ahead in the factorisation
     constexpr int BCH = MPCX_BCH;          // same, stage pairs in the Hessian build (8 doubles each)
     __shared__ QpShared<NT> sh;
     const int b = blockIdx.x;
@@ -188,14 +185,14 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     double g = 0.0;
     {
         const double coef = real ? (kind ? sh.beta[kc] : dt) : 0.0;
-        const double *bxp = sh.pre[kind ? 2 : 0], *byp = sh.pre[kind ? 3 : 1];
-        const double bx0 = bxp[kc + 1], by0 = byp[kc + 1];
+        const int rx = kind ? 2 : 0, ry = kind ? 3 : 1;          // LDS row indices (no generic pointers)
+        const double bx0 = sh.pre[rx][kc + 1], by0 = sh.pre[ry][kc + 1];
         const double cv = kind ? 0.0 : coef, cp = kind ? coef : 0.0;
 #pragma unroll
         for (int t = 1; t <= NT; t++) {
             const double act = (real && (t >= k + 1)) ? 1.0 : 0.0;     // stages t > T carry zero weights
             const double ca = act * coef;
-            const double gx = ca * (bxp[t] - bx0), gy = ca * (byp[t] - by0), gv = act * cv, gp = act * cp;
+            const double gx = ca * (sh.pre[rx][t] - bx0), gy = ca * (sh.pre[ry][t] - by0), gv = act * cv, gp = act * cp;
             const double wxx = sh.wt[t][0], wxy = sh.wt[t][1], wyy = sh.wt[t][2], wv = sh.wt[t][3], wp = sh.wt[t][4];
             sh.gb[lane][0] = wxx * gx + wxy * gy;
             sh.gb[lane][1] = wxy * gx + wyy * gy;
@@ -250,10 +247,10 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     // pristine band entries H(i,i), H(i,i+1), H(i,i-1) of this lane's row: each iteration writes "band + G'DG band"
     // into LDS so that the row can be read back without per-element selects
     const bool has_hi = lane + 1 < N, has_lo = inrow && lane >= 1;
-    double *const p_d = inrow ? &sh.H[lane * N + lane] : &sh.dump[lane];
-    double *const p_hi = has_hi ? &sh.H[(lane + 1) * N + lane] : &sh.dump[lane];
-    double *const p_lo = has_lo ? &sh.H[(lane - 1) * N + lane] : &sh.dump[lane];
-    const double h_d = *p_d, h_hi = has_hi ? *p_hi : 0.0, h_lo = has_lo ? *p_lo : 0.0;
+    const int i_d = inrow ? lane * N + lane : N * N + lane;           // LDS indices (no generic pointers)
+    const int i_hi = has_hi ? (lane + 1) * N + lane : N * N + lane;
+    const int i_lo = has_lo ? (lane - 1) * N + lane : N * N + lane;
+    const double h_d = inrow ? sh.H[i_d] : 0.0, h_hi = has_hi ? sh.H[i_hi] : 0.0, h_lo = has_lo ? sh.H[i_lo] : 0.0;
 
     // ---------------------------------------------------------------- constraints owned by this lane
     // rows 0/1: +-u_i box ; rows 2/3: accel lane k -> +-v_{k+1} speed rows, steer lane k -> +-(d_{k+1}-d_k)
@@ -269,7 +266,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     const double k0m = (k == 0) ? 0.0 : 1.0;
 
     double u = 0.0;
-    if (real && a.u_warm) u = a.u_warm[(size_t)b * 2 * T + kind * T + k];
+    if (real && a.has_warm) u = a.u_warm[(size_t)b * 2 * T + kind * T + k];
 
     // (G x) of the second row pair: accel lane: dt * sum_{j<=k} a_j ; steer lane: d_{k+1} - d_k   (DPP, no LDS)
     auto second_rows = [&](double x) -> double {
@@ -307,19 +304,22 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 
     for (it = 0; it <= max_iter; it++) {
         // -------- H u from the PRISTINE Hessian (restore the band entries the previous iteration patched)
-        *p_d = h_d; *p_hi = h_hi; *p_lo = h_lo;
+        sh.H[i_d] = h_d; sh.H[i_hi] = h_hi; sh.H[i_lo] = h_lo;
         sh.ub[lane] = u;
         lds_sync();
         double hu = 0.0;
 #pragma unroll
         for (int j = 0; j < N; j++) hu = fma(sh.H[j * N + li], sh.ub[j], hu);
         // -------- residuals
-        const double e2 = second_rows(u);
-        rd = m01 * (hu + g + gt_apply(m01 * l0, m01 * l1, m23 * l2, m23 * l3));
-        rp0 = m01 * (u + s0 - h0); rp1 = m01 * (-u + s1 - h1);
-        rp2 = m23 * (e2 + s2 - h2); rp3 = m23 * (-e2 + s3 - h3);
-        mu = wave_sum_dpp(m01 * (s0 * l0 + s1 * l1) + m23 * (s2 * l2 + s3 * l3)) * minv;
-        const double resn = wave_max_dpp(fmax(fabs(rd) * ign, fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))) * ihn));
+        double resn;
+        {
+            const double e2 = second_rows(u);
+            rd = m01 * (hu + g + gt_apply(m01 * l0, m01 * l1, m23 * l2, m23 * l3));
+            rp0 = m01 * (u + s0 - h0); rp1 = m01 * (-u + s1 - h1);
+            rp2 = m23 * (e2 + s2 - h2); rp3 = m23 * (-e2 + s3 - h3);
+            mu = wave_sum_dpp(m01 * (s0 * l0 + s1 * l1) + m23 * (s2 * l2 + s3 * l3)) * minv;
+            resn = wave_max_dpp(fmax(fabs(rd) * ign, fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))) * ihn));
+        }
 #ifdef MPCX_QP_TRACE
         if (b == MPCX_QP_TRACE && lane == 0) printf("it %d resn %.3e mu %.3e gnorm %.3e hnorm %.3e\n", it, resn, mu, gnorm, hnorm);
 #endif
@@ -334,16 +334,18 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 
         // -------- row of M = H + G'DG: the band part (diagonal + steer tridiagonal) is written into LDS so that the row
         // reads back without per-element selects; the accel block adds dt^2 * min(S_i, S_j)
-        const double is0 = frcp1(s0), is1 = frcp1(s1), is2 = frcp1(s2), is3 = frcp1(s3);
-        const double d0 = m01 * l0 * is0, d1 = m01 * l1 * is1, d2 = m23 * l2 * is2, d3 = m23 * l3 * is3;
-        const double r23 = d2 + d3;
-        const double S = scan_down32(ma * r23, lane);    // accel lanes: sum_{j>=k} (d2+d3)_j ; elsewhere 0
-        const double r_own = kind ? r23 : 0.0;
-        const double r_prev = k0m * lane_prev(r_own);
-        sh.sb[lane] = S;
-        *p_d = h_d + (d0 + d1 + r_own + r_prev);
-        *p_hi = h_hi - r_own;
-        *p_lo = h_lo - r_prev;
+        double S;
+        {
+            const double is0 = frcp1(s0), is1 = frcp1(s1), is2 = frcp1(s2), is3 = frcp1(s3);
+            const double r23 = m23 * (l2 * is2 + l3 * is3);
+            S = scan_down32(ma * r23, lane);             // accel lanes: sum_{j>=k} (d2+d3)_j ; elsewhere 0
+            const double r_own = kind ? r23 : 0.0;
+            const double r_prev = k0m * lane_prev(r_own);
+            sh.sb[lane] = S;
+            sh.H[i_d] = h_d + (m01 * (l0 * is0 + l1 * is1) + r_own + r_prev);
+            sh.H[i_hi] = h_hi - r_own;
+            sh.H[i_lo] = h_lo - r_prev;
+        }
         lds_sync();
 #pragma unroll
         for (int j = 0; j < N; j++) {
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         double dinv = 1.0;
         bool bad = false;
         double pre[2][PRE];
+        double Rlo[N];
         sh.cb[0][lane] = R[0];
         lds_order();
 #pragma unroll
@@ -375,7 +378,6 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         for (int j = 0; j < N; j++) {
             constexpr int dummy = 0; (void)dummy;
             const int p = j & 1;
-            const double *col = sh.cb[p];
             const double tj = (lane > j) ? R[j] * rinv : 0.0;          // L~(lane, j)
             double rinv_n = 1.0;
             if (j + 1 < N) {
@@ -394,14 +396,15 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
                 // loads first, then FMAs, then the (volatile) pins: a pin between two loads would serialise them
                 double cv[N];
 #pragma unroll
-                for (int kk = j + 2; kk < N; kk++) cv[kk] = (kk - (j + 1) < PRE) ? pre[p][kk - (j + 1)] : col[kk];
+                for (int kk = j + 2; kk < N; kk++) cv[kk] = (kk - (j + 1) < PRE) ? pre[p][kk - (j + 1)] : sh.cb[p][kk];
 #pragma unroll
                 for (int kk = j + 2; kk < N; kk++) R[kk] = fma(-tj, cv[kk], R[kk]);
 #pragma unroll
                 for (int kk = j + 2; kk < N; kk++) pin(R[kk]);
             }
 #endif
-            R[j] = (lane < j) ? R[j] : tj;                              // lanes < j keep their unscaled Schur entry, lane j gets 0
+            Rlo[j] = tj;                                                // unit lower factor entry (0 for lanes <= j)
+            R[j] = (lane < j) ? R[j] : 0.0;                             // lanes < j keep their unscaled Schur entry
             dinv = (lane == j) ? rinv : dinv;
             rinv = rinv_n;
             __builtin_amdgcn_sched_barrier(0);
@@ -410,13 +413,23 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         if (bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; break; }
 #endif
 
+        // Everything derived from (u, s, lam) is recomputed here instead of being kept alive across the factorisation (the
+        // pins make the compiler treat the inputs as new values): 80 VGPRs of the register file hold the factor.
+        pin(u); pin(s0); pin(s1); pin(s2); pin(s3); pin(l0); pin(l1); pin(l2); pin(l3);
+        const double is0 = frcp1(s0), is1 = frcp1(s1), is2 = frcp1(s2), is3 = frcp1(s3);
+        const double d0 = m01 * l0 * is0, d1 = m01 * l1 * is1, d2 = m23 * l2 * is2, d3 = m23 * l3 * is3;
+        {
+            const double e2 = second_rows(u);
+            rp0 = m01 * (u + s0 - h0); rp1 = m01 * (-u + s1 - h1);
+            rp2 = m23 * (e2 + s2 - h2); rp3 = m23 * (-e2 + s3 - h3);
+        }
         // -------- predictor (affine scaling) direction
         double w0 = -m01 * l0 + d0 * rp0, w1 = -m01 * l1 + d1 * rp1, w2 = -m23 * l2 + d2 * rp2, w3 = -m23 * l3 + d3 * rp3;
         double rhs = m01 * (-rd - gt_apply(w0, w1, w2, w3));
 #ifdef MPCX_SKIP_SOLVE
         double du = m01 * rhs * dinv;
 #else
-        double du = m01 * ldl_solve<N>(R, dinv, rhs, lane);
+        double du = m01 * ldl_solve<N>(Rlo, R, dinv, rhs, lane);
 #endif
         double f2 = second_rows(du);
         const double dsa0 = -rp0 - m01 * du, dsa1 = -rp1 + m01 * du, dsa2 = -rp2 - f2, dsa3 = -rp3 + f2;
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 #ifdef MPCX_SKIP_SOLVE
         du = m01 * rhs * dinv;
 #else
-        du = m01 * ldl_solve<N>(R, dinv, rhs, lane);
+        du = m01 * ldl_solve<N>(Rlo, R, dinv, rhs, lane);
 #endif
         f2 = second_rows(du);
         const double ds0 = -rp0 - m01 * du, ds1 = -rp1 + m01 * du, ds2 = -rp2 - f2, ds3 = -rp3 + f2;
@@ -511,7 +524,7 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     if (B < 0 || !x0 || !xref || !xbar || !reaches_end || !x_out || !u_out || !status || !iters || !kkt)
         return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: null pointer or negative batch");
     if (B == 0) return MPCX_OK;
-    mpcx::QpArgs a{ctx->mpc, B, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters};
+    mpcx::QpArgs a{ctx->mpc, B, u_warm != nullptr, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters};
     const int T = ctx->mpc.T;
     if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream);
     else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream);
