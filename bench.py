@@ -37,6 +37,23 @@ def agent_step_bytes(T: int, A: int) -> float:
     return 32 + 16 * T + 48 * (A - 1) + 24 * (T + 1) + 32 * (T + 1) + 16 * T + 8
 
 
+def pmc_traffic_bytes(kernel='qp_kernel'):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/r01_pmc_final.csv;
+    bench.py cannot run the profiler on itself): 2 x FETCH_SIZE (gfx950 under-reports reads by 2x, MI355X_MICROARCH.md
+    'HBM') + WRITE_SIZE, KiB -> bytes. None when the file is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_final.csv')
+    if not os.path.exists(path):
+        return None
+    vals = {}
+    for line in open(path):
+        parts = line.strip().split(',')
+        if len(parts) == 3 and kernel in parts[0] and parts[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            vals[parts[1]] = float(parts[2])
+    if len(vals) != 2:
+        return None
+    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
+
+
 def cpu_baseline(sim, snap_before, n_agents: int):
     """Oracle (CPU port of the same per-agent step, oracle/) timed on this host, single thread, on a bounded sample
     of the SAME workload: the first `n_agents` (instance, agent) pairs of rank 0's batch, from the captured state."""
@@ -161,7 +178,10 @@ def main():
             'agent_qp_per_s': value * args.agents,
             'mean_ipm_iters': mean_iters, 'qp_failures': int(fail_sum.item()),
             'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / FP64_PEAK_TFLOPS, 'traffic': None, 'kernel': 'qp_kernel<%d>' % args.horizon,
+                         'frac': achieved_tf / FP64_PEAK_TFLOPS,
+                         'traffic': pmc_traffic_bytes() if (args.horizon == 20 and args.batch == 4096 and args.agents == 8) else None,
+                         'traffic_note': 'HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (profiles/r01_pmc_final.csv), same workload; algorithmic bytes per launch = %.3g' % (P * (32 + 2 * 32 * (args.horizon + 1) + (args.horizon + 1) + 16 * args.horizon + 32 * (args.horizon + 1) + 16 * args.horizon + 40)),
+                         'kernel': 'qp_kernel<%d>' % args.horizon,
                          'kernel_ms': qp_ms, 'flops_per_qp': qp_flops(args.horizon, mean_iters),
                          'note': 'FP64 compute bound (MI355X FP64 matrix rate == FP64 vector rate, 78.6 TFLOP/s); algorithmic flops of '
                                  'SURVEY 8(d) x measured mean IPM iterations / HIP-event kernel time; the kernel issues FP64 VALU FMAs, not MFMA'},
