@@ -102,10 +102,17 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path is HIP-only')
+    # rehearsal knob (single-GPU box): several ranks may share cuda:0 over gloo; the driver's runs use RCCL, one GPU per rank
+    backend = os.environ.get('MPCX_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mpc_for_av_at_intersection_amd.batch import synthetic_batch
     from mpc_for_av_at_intersection_amd.runtime import Context
@@ -115,7 +122,10 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if backend == 'nccl':
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     iters_sum = torch.zeros((), dtype=torch.float64, device=ctx.device)
@@ -152,7 +162,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.qp_solve = orig_qp
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device if backend == 'nccl' else 'cpu')
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
