@@ -20,6 +20,9 @@
 #ifndef MPCX_CHUNK
 #define MPCX_CHUNK 40
 #endif
+#ifndef MPCX_SPLIT
+#define MPCX_SPLIT 1
+#endif
 #ifndef MPCX_PRE
 #define MPCX_PRE 8
 #endif
@@ -55,10 +58,10 @@ struct QpShared {
                             // the last WAVE slots are a write sink for lanes that have no band entry to patch
     double pre[6][NT + 1];  // exclusive prefix sums over t: Px, Py (accel paths), Qx, Qy (steer paths), Cx, Cy (affine)
     double beta[32];        // dt * vbar_k / L
-    double wt[33][6];       // per-t cost weights: wxx, wxy, wyy, wv, wyaw
+    double wt[33][6];       // per-t cost weights: wxx, wxy, wyy, wv, wyaw (padded to 48 B so rows stay 16-B aligned)
     double we[NT + 1][4];   // W_t * (free response - reference)
     double gb[WAVE][4];     // W_t * sensitivity of every unknown at the current t (Hessian build broadcast)
-    double cb[2][WAVE];     // Cholesky column broadcast (double buffered)
+    double cb[2][WAVE];     // factorisation column broadcast (double buffered)
     double ub[WAVE];        // current iterate broadcast
     double sb[WAVE];        // speed-row suffix sums broadcast
 };
@@ -98,6 +101,29 @@ __device__ __forceinline__ double ldl_solve(const double (&Rlo)[N], const double
 #pragma unroll
     for (int j = N - 1; j >= 0; j--) sum = fma(Rup[j], rdlane(fma(-dinv, sum, w), j), sum);
     return fma(-dinv, sum, w);
+}
+
+// Single-array variant (MPCX_SPLIT=0): lane i keeps L~(i,k) for k<i and the unscaled Schur entries for k>i in ONE array (80
+// VGPRs less); a finished lane's accumulators are then disturbed by later steps, so each sweep captures its result.
+template <int N>
+__device__ __forceinline__ double ldl_solve1(const double (&R)[N], double dinv, double b, int lane) {
+    double acc = b, z = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const double zj = rdlane(acc, j);
+        z = (lane == j) ? acc : z;
+        acc = fma(-R[j], zj, acc);
+    }
+    const double w = z * dinv;
+    double sum = 0.0, x = 0.0;
+#pragma unroll
+    for (int j = N - 1; j >= 0; j--) {
+        const double tmp = fma(-dinv, sum, w);
+        const double xj = rdlane(tmp, j);
+        x = (lane == j) ? tmp : x;
+        sum = fma(R[j], xj, sum);
+    }
+    return x;
 }
 
 template <int NT>
@@ -363,7 +389,12 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         double dinv = 1.0;
         bool bad = false;
         double pre[2][PRE];
+#if MPCX_SPLIT
         double Rlo[N];
+#define SOLVE(b_) ldl_solve<N>(Rlo, R, dinv, b_, lane)
+#else
+#define SOLVE(b_) ldl_solve1<N>(R, dinv, b_, lane)
+#endif
         sh.cb[0][lane] = R[0];
         lds_order();
 #pragma unroll
@@ -403,8 +434,12 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
                 for (int kk = j + 2; kk < N; kk++) pin(R[kk]);
             }
 #endif
+#if MPCX_SPLIT
             Rlo[j] = tj;                                                // unit lower factor entry (0 for lanes <= j)
             R[j] = (lane < j) ? R[j] : 0.0;                             // lanes < j keep their unscaled Schur entry
+#else
+            R[j] = (lane < j) ? R[j] : tj;                              // lanes < j keep their unscaled Schur entry, lane j gets 0
+#endif
             dinv = (lane == j) ? rinv : dinv;
             rinv = rinv_n;
             __builtin_amdgcn_sched_barrier(0);
@@ -429,7 +464,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 #ifdef MPCX_SKIP_SOLVE
         double du = m01 * rhs * dinv;
 #else
-        double du = m01 * ldl_solve<N>(Rlo, R, dinv, rhs, lane);
+        double du = m01 * SOLVE(rhs);
 #endif
         double f2 = second_rows(du);
         const double dsa0 = -rp0 - m01 * du, dsa1 = -rp1 + m01 * du, dsa2 = -rp2 - f2, dsa3 = -rp3 + f2;
@@ -458,7 +493,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 #ifdef MPCX_SKIP_SOLVE
         du = m01 * rhs * dinv;
 #else
-        du = m01 * ldl_solve<N>(Rlo, R, dinv, rhs, lane);
+        du = m01 * SOLVE(rhs);
 #endif
         f2 = second_rows(du);
         const double ds0 = -rp0 - m01 * du, ds1 = -rp1 + m01 * du, ds2 = -rp2 - f2, ds3 = -rp3 + f2;
