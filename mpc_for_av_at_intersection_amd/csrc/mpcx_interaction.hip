@@ -7,10 +7,11 @@
 //   lib/collision_avoidance.py:66-104         check_collision_moving_cars
 //   lib/collision_avoidance.py:107-119 + mpc_intersection.py:129-136  cut-off index
 // One wavefront per ego.  The reference flattens (frame, agent disc, obstacle x frame-offset, obstacle disc)
-// into one pair table and takes the first row within 2*radius; here the obstacle disc positions (<= 16*64*2)
-// are first culled exactly against the bounding box of the ego's predicted discs, survivors are tested
-// against every frame whose +-frame_window shift reaches them, and the FIRST ROW IN THE REFERENCE'S ORDER is
-// recovered as the minimum of an integer key over all hits (bit-exact index outputs).
+// into one pair table and takes the first row within 2*radius; here every obstacle disc position (<= 16*64*2,
+// one global load each) is culled exactly against the bounding box of all ego discs and then against the boxes
+// of 8 runs of ego frames, compared only with the frames of surviving runs that a +-frame_window shift can
+// reach, and the FIRST ROW IN THE REFERENCE'S ORDER is recovered as the minimum of an integer key over all hits
+// (bit-exact index outputs).
 #include "mpcx_common.h"
 
 namespace mpcx {
@@ -64,6 +65,15 @@ __device__ __forceinline__ double dist2d(double ax, double ay, double bx, double
     const double dx = __dadd_rn(ax, -bx), dy = __dadd_rn(ay, -by);
     return __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
 }
+// dist2d(a,b) <= md, decided from the squared distance except within 1e-12 (relative) of the threshold, where the
+// reference's own expression sqrt(dx*dx + dy*dy) <= md is evaluated: identical decisions, no sqrt on the bulk of the pairs
+__device__ __forceinline__ bool within(double ax, double ay, double bx, double by, double md, double md2lo, double md2hi) {
+    const double dx = __dadd_rn(ax, -bx), dy = __dadd_rn(ay, -by);
+    const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+    if (d2 > md2hi) return false;
+    if (d2 < md2lo) return true;
+    return __dsqrt_rn(d2) <= md;
+}
 __device__ __forceinline__ long long wave_min_ll(long long v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { long long o = __shfl_xor(v, s, WAVE); v = o < v ? o : v; }
@@ -81,8 +91,9 @@ __device__ __forceinline__ int wave_min_i(int v) {
 constexpr int NSEG = 8;
 __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)[4], int na, const double *pred,
                               int ooff, int nobs, int oskip, const double *rem, const double *rcs, int n,
-                              int *s_cand, double (*s_box)[4], int lane, double &hx, double &hy) {
+                              double (*s_box)[4], int lane, double &hx, double &hy) {
     const double md = 2.0 * ip.radius;
+    const double md2lo = md * md * (1.0 - 1e-12), md2hi = md * md * (1.0 + 1e-12);
     const int steps = ip.pred_steps, w = ip.frame_window;
     double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
     for (int f = lane; f < na; f += WAVE) {
@@ -96,30 +107,10 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
     const double slack = md * (1.0 + 1e-9) + 1e-9;      // conservative: never culls a pair within md
     bx0 -= slack; by0 -= slack; bx1 += slack; by1 += slack;
 
-    // ---- cull obstacle disc positions against the box (exact: a culled disc is farther than md from every ego disc)
-    const int ncand_all = nobs * steps * 2;
-    int cbase = 0;
-    for (int c0 = 0; c0 < ncand_all; c0 += WAVE) {
-        const int cidx = c0 + lane;
-        bool keep = false;
-        if (cidx < ncand_all) {
-            const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;   // o: local obstacle rank
-            int pool = ooff + o;
-            if (oskip >= 0 && pool >= oskip) pool += 1;                                    // skip self
-            const double *q = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
-            keep = (q[0] >= bx0) && (q[0] <= bx1) && (q[1] >= by0) && (q[1] <= by1);
-        }
-        const unsigned long long m = __ballot(keep);
-        const int pos = cbase + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) s_cand[pos] = cidx;
-        cbase += __popcll(m);
-    }
-    const int ncand = cbase;
-    __syncthreads();
-
-    // ---- exact test of survivors; key = reference row order (frame, agent disc, obstacle, offset, obstacle disc).
-    // Second, finer exact cull: the F frames are cut into NSEG runs, each with the bounding box of its ego discs; a survivor
-    // is only compared with the frames of runs whose (inflated) box contains it.
+    // ---- exact hierarchical cull + test.  Every obstacle disc position (one global load each) is compared with the box of
+    // ALL ego discs, then with the boxes of NSEG runs of frames, and only inside a surviving run with the ego discs of the
+    // frames whose +-window shift reaches it.  Boxes are inflated by slack > md, so no pair within md is ever skipped.
+    // key = reference row order (frame, agent disc, obstacle, offset, obstacle disc).
     const int F = na > steps ? na : steps;
     const int SL = (F + NSEG - 1) / NSEG;                 // frames per run
     if (lane < NSEG) {
@@ -137,30 +128,29 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
     __syncthreads();
     const long long NOKEY = 0x7fffffffffffffffLL;
     long long best = NOKEY;
-    const int npairs = ncand * NSEG;
-    for (int q0 = 0; q0 < npairs; q0 += WAVE) {
-        const int qi = q0 + lane;
-        if (qi < npairs) {
-            const int ci = qi / NSEG, sg = qi % NSEG;
-            const int cidx = s_cand[ci];
-            const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;
-            int pool = ooff + o;
-            if (oskip >= 0 && pool >= oskip) pool += 1;
-            const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
-            const double ox = qq[0], oy = qq[1];
-            if (ox >= s_box[sg][0] && ox <= s_box[sg][1] && oy >= s_box[sg][2] && oy <= s_box[sg][3]) {
-                const int f1 = (sg + 1) * SL < F ? (sg + 1) * SL : F;
-                for (int f = sg * SL; f < f1; f++) {
-                    const int ff = f < steps ? f : steps - 1;
-                    if (abs(g - ff) > w) continue;       // no offset d in [-w, w] maps padded frame ff onto obstacle frame g
-                    const int fe = f < na ? f : na - 1;
+    const int ncand_all = nobs * steps * 2;
+    for (int c0 = 0; c0 < ncand_all; c0 += WAVE) {
+        const int cidx = c0 + lane;
+        if (cidx >= ncand_all) continue;
+        const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;   // o: local obstacle rank
+        int pool = ooff + o;
+        if (oskip >= 0 && pool >= oskip) pool += 1;                                    // skip self
+        const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
+        const double ox = qq[0], oy = qq[1];
+        if (!((ox >= bx0) && (ox <= bx1) && (oy >= by0) && (oy <= by1))) continue;
+        for (int sg = 0; sg < NSEG; sg++) {
+            if (!(ox >= s_box[sg][0] && ox <= s_box[sg][1] && oy >= s_box[sg][2] && oy <= s_box[sg][3])) continue;
+            const int f1 = (sg + 1) * SL < F ? (sg + 1) * SL : F;
+            for (int f = sg * SL; f < f1; f++) {
+                const int ff = f < steps ? f : steps - 1;
+                if (abs(g - ff) > w) continue;       // no offset d in [-w, w] maps padded frame ff onto obstacle frame g
+                const int fe = f < na ? f : na - 1;
 #pragma unroll
-                    for (int ca = 0; ca < 2; ca++) {
-                        if (dist2d(s_ego[fe][2 * ca], s_ego[fe][2 * ca + 1], ox, oy) <= md) {
-                            // offsets ascend => obstacle frames descend; the first offset reaching g is the one that counts
-                            const long long key = ((((long long)f * 2 + ca) * MPCX_MAX_OBS + o) * MPCX_PRED_STEPS_MAX + (steps - 1 - g)) * 2 + co;
-                            best = key < best ? key : best;
-                        }
+                for (int ca = 0; ca < 2; ca++) {
+                    if (within(s_ego[fe][2 * ca], s_ego[fe][2 * ca + 1], ox, oy, md, md2lo, md2hi)) {
+                        // offsets ascend => obstacle frames descend; the first offset reaching g is the one that counts
+                        const long long key = ((((long long)f * 2 + ca) * MPCX_MAX_OBS + o) * MPCX_PRED_STEPS_MAX + (steps - 1 - g)) * 2 + co;
+                        best = key < best ? key : best;
                     }
                 }
             }
@@ -185,7 +175,7 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
             const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
             const double ex = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
             const double ey = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
-            if (dist2d(ox, oy, ex, ey) <= md) { const int key = d * n + i; first = key < first ? key : first; }
+            if (within(ox, oy, ex, ey, md, md2lo, md2hi)) { const int key = d * n + i; first = key < first ? key : first; }
         }
     }
     first = wave_min_i(first);
@@ -196,13 +186,11 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
 
 constexpr int MAXREM = MPCX_MAX_REMAINING;
 constexpr int MAXF = MPCX_EGO_FRAMES_MAX;
-constexpr int MAXCAND = MPCX_MAX_OBS * MPCX_PRED_STEPS_MAX * 2;
 
 __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     __shared__ double s_cum[MAXREM];
     __shared__ int s_keep[MAXF];
     __shared__ double s_ego[MAXF][4];     // ego disc centres per kept pose: (x0,y0,x1,y1)
-    __shared__ int s_cand[MAXCAND];       // surviving obstacle disc ids: (o*steps + g)*2 + co
     __shared__ double s_box[NSEG][4];     // bounding boxes of the ego discs per run of frames
 
     const int p = blockIdx.x, lane = threadIdx.x;
@@ -219,7 +207,49 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
         advance = (path[3 * tidx] != path[3 * last]) || (path[3 * tidx + 1] != path[3 * last + 1]) ||
                   (path[3 * tidx + 2] != path[3 * last + 2]);
     }
-    if (advance) tidx = nearest_index_in_direction(path, len, tidx, x, y, lane);
+    const int t_old = tidx;
+    const int n_old = len - t_old;
+    const int nobs = a.obs_cnt[p] - ((a.obs_skip && a.obs_skip[p] >= 0) ? 1 : 0);
+    if (n_old > MAXREM || nobs > MPCX_MAX_OBS) {
+        if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        return;
+    }
+    // ONE pass over the remaining path: distances to the ego (per-lane three smallest, ties by lower index) for
+    // trajectories.py:100-126, and the step lengths |p_i - p_{i-1}| for resample_curve (trajectories.py:72-75)
+    double b0d = INFINITY, b1d = INFINITY, b2d = INFINITY;
+    int b0i = 0x7fffffff, b1i = 0x7fffffff, b2i = 0x7fffffff;
+    for (int i = lane; i < n_old; i += WAVE) {
+        const double *q = path + 3 * (size_t)(t_old + i);
+        const double px = q[0], py = q[1];
+        s_cum[i] = (i == 0) ? 0.0 : dist2d(px, py, q[-3], q[-2]);
+        if (advance) {
+            const double d = dist2d(px, py, x, y);
+            if (d < b2d || (d == b2d && i < b2i)) {
+                if (d < b1d || (d == b1d && i < b1i)) {
+                    b2d = b1d; b2i = b1i;
+                    if (d < b0d || (d == b0d && i < b0i)) { b1d = b0d; b1i = b0i; b0d = d; b0i = i; }
+                    else { b1d = d; b1i = i; }
+                } else { b2d = d; b2i = i; }
+            }
+        }
+    }
+    if (advance) {
+        if (n_old <= 1) tidx = t_old;
+        else if (n_old == 2) tidx = t_old + 1;
+        else {
+            int bi[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {     // pop the wave-wide minimum three times
+                double d = b0d; int ix = b0i;
+                wave_argmin(d, ix);
+                bi[r] = ix;
+                if (b0i == ix) { b0d = b1d; b0i = b1i; b1d = b2d; b1i = b2i; b2d = INFINITY; b2i = 0x7fffffff; }
+            }
+            if (abs(bi[1] - bi[2]) == 2) tidx = bi[0] + t_old;
+            else if (abs(bi[0] - bi[1]) == 1) tidx = max(bi[0], bi[1]) + t_old;
+            else tidx = -1;
+        }
+    }
     if (tidx < 0) {
         if (lane == 0) { a.hit_idx[p] = -3; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
@@ -228,53 +258,49 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     const double *rem = path + 3 * (size_t)tidx;      // trajectory = trajectory_full[traj_agent_idx:]
     const double *rcs = pcs + 2 * (size_t)tidx;
     const int n = len - tidx;
-    const int nobs = a.obs_cnt[p] - ((a.obs_skip && a.obs_skip[p] >= 0) ? 1 : 0);
-    if (n > MAXREM || nobs > MPCX_MAX_OBS) {
-        if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
-        return;
-    }
+    const int shift = tidx - t_old;                   // s_cum[shift + i] = step length into point i of the new trajectory
     if (nobs <= 0) {    // collision_avoidance.py:69-70
         if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
     }
-
-    // ---- mpc_intersection.py:110-116 + trajectories.py:72-86: ego prediction = resample_curve(trajectory, dl_k)
-    for (int i = lane; i < n; i += WAVE)
-        s_cum[i] = (i == 0) ? 0.0 : dist2d(rem[3 * i], rem[3 * i + 1], rem[3 * (i - 1)], rem[3 * (i - 1) + 1]);
     __syncthreads();
+    // ---- mpc_intersection.py:110-116 + trajectories.py:72-86: ego prediction = resample_curve(trajectory, dl_k)
     if (lane == 0) {                      // np.cumsum: strictly sequential adds (one lane; loads batched 16 at a time)
         double c = 0.0;
-        int i = 0;
+        s_cum[shift] = 0.0;               // the first point of the new trajectory has no predecessor
+        int i = 1;
         for (; i + 16 <= n; i += 16) {
             double t[16];
 #pragma unroll
-            for (int q = 0; q < 16; q++) t[q] = s_cum[i + q];
+            for (int q = 0; q < 16; q++) t[q] = s_cum[shift + i + q];
 #pragma unroll
             for (int q = 0; q < 16; q++) { c = __dadd_rn(c, t[q]); t[q] = c; }
 #pragma unroll
-            for (int q = 0; q < 16; q++) s_cum[i + q] = t[q];
+            for (int q = 0; q < 16; q++) s_cum[shift + i + q] = t[q];
         }
-        for (; i < n; i++) { c = __dadd_rn(c, s_cum[i]); s_cum[i] = c; }
+        for (; i < n; i++) { c = __dadd_rn(c, s_cum[shift + i]); s_cum[shift + i] = c; }
     }
     __syncthreads();
     const bool accel_phase = v < ip.max_speed;
     const double dl_const = __dmul_rn(ip.dt, ip.max_speed);
     int base = 0;
     bool overflow = false;
+    long long q_carry = 0;                // bucket of the last element of the previous 64-block
     for (int i0 = 0; i0 < n; i0 += WAVE) {
         const int i = i0 + lane;
-        bool keep = false;
+        long long q = 0;
         if (i < n) {
-            auto qof = [&](int j) -> long long {
-                double dl = dl_const;
-                if (accel_phase) {
-                    const double r = __dadd_rn(__dmul_rn(ip.max_accel, (double)(j + 1)), v);   // cumsum of equal terms (exact for 2.0) + v
-                    dl = __dmul_rn(ip.dt, fmin(r, ip.max_speed));
-                }
-                return (long long)floor(__ddiv_rn(s_cum[j], dl));
-            };
-            keep = (i == 0) || (i == n - 1) || (qof(i) - qof(i - 1) >= 1);
+            double dl = dl_const;
+            if (accel_phase) {
+                const double r = __dadd_rn(__dmul_rn(ip.max_accel, (double)(i + 1)), v);   // cumsum of equal terms (exact for 2.0) + v
+                dl = __dmul_rn(ip.dt, fmin(r, ip.max_speed));
+            }
+            q = (long long)floor(__ddiv_rn(s_cum[shift + i], dl));
         }
+        long long qprev = __shfl_up(q, 1, WAVE);
+        if (lane == 0) qprev = q_carry;
+        q_carry = __shfl(q, WAVE - 1, WAVE);
+        const bool keep = (i < n) && ((i == 0) || (i == n - 1) || (q - qprev >= 1));
         const unsigned long long m = __ballot(keep);
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
         if (keep) { if (pos < MAXF) s_keep[pos] = i; else overflow = true; }
@@ -301,7 +327,7 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     __syncthreads();
     const int ooff = a.obs_off[p], oskip = a.obs_skip ? a.obs_skip[p] : -1;
     double hx, hy;
-    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_cand, s_box, lane, hx, hy);
+    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, lane, hx, hy);
     if (first < 0) {
         if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
@@ -352,7 +378,6 @@ struct MovArgs {
 
 __global__ __launch_bounds__(64) void moving_collision_kernel(MovArgs a) {
     __shared__ double s_ego[MAXF][4];
-    __shared__ int s_cand[MAXCAND];
     __shared__ double s_box[NSEG][4];
     const int p = blockIdx.x, lane = threadIdx.x;
     const mpcx_interaction_params &ip = a.ip;
@@ -372,7 +397,7 @@ __global__ __launch_bounds__(64) void moving_collision_kernel(MovArgs a) {
     __syncthreads();
     double hx, hy;
     const int first = first_conflict(ip, s_ego, na, a.pred, a.obs_off[p], nobs, -1,
-                                     a.path + 3 * (size_t)a.path_off[p], a.path_cs + 2 * (size_t)a.path_off[p], n, s_cand, s_box, lane, hx, hy);
+                                     a.path + 3 * (size_t)a.path_off[p], a.path_cs + 2 * (size_t)a.path_off[p], n, s_box, lane, hx, hy);
     if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = first < 0 ? 0.0 : hx; a.hit_xy[2 * p + 1] = first < 0 ? 0.0 : hy; }
 }
 
