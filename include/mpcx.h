@@ -77,10 +77,12 @@ int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B,
  * (+ simulation.py:35-47, bicycle/main.py:28-41).  Paths are ragged: instance b tracks points
  * [path_off[b], path_off[b]+path_len[b]) of path_xyyaw (rows x,y,yaw; yaw already smooth_yaw'ed);
  * path_len[b] is the CURRENT (possibly cut) length, as after MPC.set_trajectory_fromarray.
- * target_ind is in-out (mpc.py:226).  target_ind[b] = -1 on the reference's Exception("something wrong"). */
+ * target_ind is in-out (mpc.py:226).  target_ind[b] = -1 on the reference's Exception("something wrong").
+ * path_v (NULL for lib/mpc.py) is the speed profile `cv` of lib/mpc_with_speed.py:85-108: xref[2,:] = cv[idx]. */
 int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double *state /*B,4: x,y,v,yaw*/,
                                const double *u_warm /*B,2,T or NULL*/,
-                               const double *path_xyyaw /*npts,3*/, const int32_t *path_off /*B*/,
+                               const double *path_xyyaw /*npts,3*/, const double *path_v /*npts or NULL*/,
+                               const int32_t *path_off /*B*/,
                                const int32_t *path_len /*B*/, double dl, int32_t *target_ind /*B in-out*/,
                                double *xref /*B,4,T+1*/, uint8_t *reaches_end /*B,T+1*/, double *xbar /*B,4,T+1*/);
 

@@ -51,7 +51,7 @@ def load():
     lib.mpcx_set_mpc_params.restype = i32; lib.mpcx_set_mpc_params.argtypes = [vp, C.POINTER(MpcParamsC)]
     lib.mpcx_qp_solve_batch.restype = i32; lib.mpcx_qp_solve_batch.argtypes = [vp, i32] + [vp] * 10
     lib.mpcx_mpc_prepare_batch.restype = i32
-    lib.mpcx_mpc_prepare_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.c_double, vp, vp, vp, vp]
+    lib.mpcx_mpc_prepare_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp, vp, vp]
     lib.mpcx_search_model_create.restype = vp
     lib.mpcx_search_model_create.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.mpcx_search_model_destroy.restype = None; lib.mpcx_search_model_destroy.argtypes = [vp]

@@ -14,7 +14,7 @@ namespace mpcx {
 struct RefArgs {
     mpcx_mpc_params p;
     int B;
-    const double *state, *path;
+    const double *state, *path, *path_v;
     const int32_t *path_off, *path_len;
     double dl;
     int32_t *target_ind;
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(64) void ref_window_kernel(RefArgs a) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int T = a.p.T, W = T + 1;
     const double *path = a.path + 3 * (size_t)a.path_off[b];
+    const double *pv = a.path_v ? a.path_v + (size_t)a.path_off[b] : nullptr;   // mpc_with_speed.py:103-104
     const int n = a.path_len[b];
     const double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2];
     int start = a.target_ind[b];
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(64) void ref_window_kernel(RefArgs a) {
         if (idx > n - 1) idx = n - 1;
         xr[0 * W + lane] = path[3 * idx];
         xr[1 * W + lane] = path[3 * idx + 1];
-        xr[2 * W + lane] = 0.0;
+        xr[2 * W + lane] = pv ? pv[idx] : 0.0;
         xr[3 * W + lane] = path[3 * idx + 2];
         re[lane] = (idx == n - 1);
     }
@@ -119,14 +120,14 @@ __global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
 }  // namespace mpcx
 
 extern "C" int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double *state, const double *u_warm,
-                                          const double *path_xyyaw, const int32_t *path_off, const int32_t *path_len,
-                                          double dl, int32_t *target_ind, double *xref, uint8_t *reaches_end, double *xbar) {
+                                          const double *path_xyyaw, const double *path_v, const int32_t *path_off,
+                                          const int32_t *path_len, double dl, int32_t *target_ind, double *xref, uint8_t *reaches_end, double *xbar) {
     if (!ctx) return MPCX_E_INVALID;
     if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");
     if (B < 0 || !state || !path_xyyaw || !path_off || !path_len || !target_ind || !xref || !reaches_end || !xbar || !(dl > 0))
         return mpcx_fail(ctx, MPCX_E_INVALID, "mpc_prepare_batch: null pointer, negative batch or dl <= 0");
     if (B == 0) return MPCX_OK;
-    mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_off, path_len, dl, target_ind, xref, reaches_end};
+    mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end};
     hipLaunchKernelGGL(mpcx::ref_window_kernel, dim3(B), dim3(64), 0, ctx->stream, ra);
     mpcx::RollArgs ro{ctx->mpc, B, state, u_warm, xbar};
     hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, ro);

@@ -150,7 +150,7 @@ class Context:
                                                _ptr(out['iters']), _ptr(out['kkt'])))
         return out
 
-    def prepare(self, state, u_warm, path, path_off, path_len, dl, target_ind, out=None):
+    def prepare(self, state, u_warm, path, path_off, path_len, dl, target_ind, out=None, path_v=None):
         """mpcx_mpc_prepare_batch. target_ind is updated in place. Returns dict(xref, reaches_end, xbar)."""
         T = self.params.T
         B = state.shape[0]
@@ -164,7 +164,7 @@ class Context:
             out = dict(xref=torch.empty((B, 4, T + 1), dtype=f, device=self.device),
                        reaches_end=torch.empty((B, T + 1), dtype=torch.uint8, device=self.device),
                        xbar=torch.empty((B, 4, T + 1), dtype=f, device=self.device))
-        self._chk(self.lib.mpcx_mpc_prepare_batch(self._ctx, B, _ptr(state), _ptr(u_warm), _ptr(path), _ptr(path_off),
+        self._chk(self.lib.mpcx_mpc_prepare_batch(self._ctx, B, _ptr(state), _ptr(u_warm), _ptr(path), _ptr(path_v), _ptr(path_off),
                                                   _ptr(path_len), C.c_double(float(dl)), _ptr(target_ind),
                                                   _ptr(out['xref']), _ptr(out['reaches_end']), _ptr(out['xbar'])))
         return out

@@ -75,8 +75,8 @@ int32_t orc_nearest_index_in_direction(double x, double y, const double *cx, con
 
 /* ------------------------------------------------------------------ lib/mpc.py:86-109 */
 int32_t orc_calc_ref_trajectory(const orc_mpc_params *p, const double *st, const double *cx, const double *cy,
-                                const double *cyaw, int32_t n, double dl, int32_t start_idx,
-                                double *xref, uint8_t *reaches_end) {
+                                const double *cyaw, const double *cv /* NULL: lib/mpc.py; else mpc_with_speed.py:103-104 */,
+                                int32_t n, double dl, int32_t start_idx, double *xref, uint8_t *reaches_end) {
     int32_t T = p->T, W = T + 1;
     int32_t s = orc_nearest_index_in_direction(st[0], st[1], cx, cy, n, start_idx, 1);
     if (s < 0) return -1;
@@ -89,7 +89,7 @@ int32_t orc_calc_ref_trajectory(const orc_mpc_params *p, const double *st, const
         if (idx > n - 1) idx = n - 1;
         xref[0 * W + k] = cx[idx];
         xref[1 * W + k] = cy[idx];
-        xref[2 * W + k] = 0.0;
+        xref[2 * W + k] = cv ? cv[idx] : 0.0;
         xref[3 * W + k] = cyaw[idx];
         reaches_end[k] = (idx == n - 1);
     }

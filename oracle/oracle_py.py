@@ -126,13 +126,15 @@ def nearest_index_in_direction(x, y, cx, cy, start, forward=True):
     return lib().orc_nearest_index_in_direction(float(x), float(y), _d(cx), _d(cy), len(cx), int(start), int(forward))
 
 
-def calc_ref_trajectory(p: MpcParams, state4, cx, cy, cyaw, dl, start_idx):
+def calc_ref_trajectory(p: MpcParams, state4, cx, cy, cyaw, dl, start_idx, cv=None):
     cx = np.ascontiguousarray(cx, np.float64); cy = np.ascontiguousarray(cy, np.float64)
     cyaw = np.ascontiguousarray(cyaw, np.float64)
     st = np.ascontiguousarray(state4, np.float64)
     xref = np.zeros((4, p.T + 1)); re = np.zeros(p.T + 1, np.uint8)
     cp = p.c()
-    s = lib().orc_calc_ref_trajectory(C.byref(cp), _d(st), _d(cx), _d(cy), _d(cyaw), C.c_int32(len(cx)), C.c_double(dl),
+    cvv = None if cv is None else np.ascontiguousarray(cv, np.float64)
+    s = lib().orc_calc_ref_trajectory(C.byref(cp), _d(st), _d(cx), _d(cy), _d(cyaw), None if cvv is None else _d(cvv),
+                                      C.c_int32(len(cx)), C.c_double(dl),
                                       C.c_int32(start_idx), _d(xref), _b(re))
     return xref, s, re
 

@@ -281,6 +281,33 @@ def stage_numpy():
         pre['T%d/oa' % T] = np.array(c_oa); pre['T%d/od' % T] = np.array(c_od); pre['T%d/xbar' % T] = np.array(c_xbar)
     rmpc.T = 13
     rmpc.Qf = np.diag([1.0, 1.0, 0.0, 0.5]) * 13
+    # speed-reference variant: window of lib/mpc_with_speed.py (numpy-only part; xref[2,:] = cv[idx])
+    import lib.mpc_with_speed as rmpcs
+    for T in (13, 20):
+        rmpcs.T = T
+        ws_state, ws_cut, ws_start, ws_xref, ws_tind, ws_re, ws_cutoff = [], [], [], [], [], [], []
+        full = paths[(4, 1)].copy()
+        rmpc.smooth_yaw(full[:, 2])
+        for case in range(24):
+            cut = len(full) if case % 2 else int(rng.integers(100, len(full)))
+            path = full[:cut]
+            i0 = int(rng.integers(0, cut - 3))
+            cutoff = 999 if case % 3 else int(rng.integers(i0, cut))
+            cv = np.full(cut, rmpcs.MAX_SPEED)
+            if cutoff != 999:
+                cv[cutoff:] = 0
+            st = State(x=path[i0, 0] + rng.normal(0, 0.2), y=path[i0, 1] + rng.normal(0, 0.2), yaw=path[i0, 2], v=float(rng.uniform(0, 8)))
+            start = max(0, i0 - 2)
+            dl = float(np.linalg.norm(full[0, :2] - full[1, :2]))
+            xref, tind, dref, re = rmpcs._calc_ref_trajectory(st, path[:, 0], path[:, 1], cv, path[:, 2], dl, 0.2, start, None)
+            ws_state.append([st.x, st.y, st.v, st.yaw]); ws_cut.append(cut); ws_start.append(start); ws_xref.append(xref)
+            ws_tind.append(tind); ws_re.append(re); ws_cutoff.append(cutoff)
+        pre['ws%d/state' % T] = np.array(ws_state); pre['ws%d/cut' % T] = np.array(ws_cut, dtype=np.int32)
+        pre['ws%d/start' % T] = np.array(ws_start, dtype=np.int32); pre['ws%d/xref' % T] = np.array(ws_xref)
+        pre['ws%d/target_ind' % T] = np.array(ws_tind, dtype=np.int32); pre['ws%d/reaches_end' % T] = np.array(ws_re, dtype=np.uint8)
+        pre['ws%d/cutoff' % T] = np.array(ws_cutoff, dtype=np.int32)
+    pre['ws/MAX_SPEED'] = np.array(rmpcs.MAX_SPEED)
+    rmpcs.T = 13
     for (sp, ti), tr in paths.items():
         pre['path_%d_%d' % (sp, ti)] = tr  # raw A* trajectory (yaw NOT yet smoothed)
     # smooth_yaw vectors
