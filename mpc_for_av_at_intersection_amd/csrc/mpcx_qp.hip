@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     const double ign = 1.0 / gnorm, ihn = 1.0 / hnorm;
 
     int status = MPCX_QP_MAXITER;
-    int it = 0;
+    int it = 0, loose_run = 0;
     double mu = 0, rd = 0, rp0 = 0, rp1 = 0, rp2 = 0, rp3 = 0;
     const double dt2 = dt * dt;
     const double tol_loose = P.tol > 1e-7 ? P.tol : 1e-7;
@@ -356,6 +356,10 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 #endif
         // reduced-accuracy acceptance when the iteration cannot continue (the reference accepts ECOS's OPTIMAL_INACCURATE, mpc.py:196)
         const bool loose = resn <= tol_loose && mu <= tol_loose;
+        // stagnation exit: the stationarity residual of badly conditioned instances stalls at its rounding floor while mu keeps
+        // collapsing; after 4 consecutive reduced-accuracy iterates stop before the factorisation degrades them
+        loose_run = loose ? loose_run + 1 : 0;
+        if (loose_run >= 4) { status = MPCX_QP_OPTIMAL; break; }
         if (it == max_iter) { if (loose) status = MPCX_QP_OPTIMAL; break; }
 
         // -------- row of M = H + G'DG: the band part (diagonal + steer tridiagonal) is written into LDS so that the row

@@ -272,7 +272,7 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
     int32_t status = ORC_MAXITER, it = 0;
     double res_d = 0, res_p = 0, mu = 0;
     const double tol_loose = p->tol > 1e-7 ? p->tol : 1e-7;
-    int loose = 0;
+    int loose = 0, loose_run = 0;
 
     /* x[2,0] bounds are constant rows (mpc.py:187-188 include t=0) */
     if (x0[2] > p->max_speed + 1e-9 || x0[2] < p->min_speed - 1e-9) { status = ORC_INFEASIBLE; goto done; }
@@ -307,6 +307,10 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
         /* reduced-accuracy acceptance when the iteration cannot continue (the reference accepts ECOS's
          * OPTIMAL_INACCURATE too, mpc.py:196) */
         loose = (res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose);
+        /* stagnation exit: the stationarity residual of badly conditioned instances stalls at its rounding floor while mu keeps
+         * collapsing; after 4 consecutive reduced-accuracy iterates stop before the factorisation degrades them */
+        loose_run = loose ? loose_run + 1 : 0;
+        if (loose_run >= 4) { status = ORC_OK; break; }
         if (it == p->max_iter) { if (loose) status = ORC_OK; break; }
         /* M = H + G' D G */
         memcpy(M, H, sizeof(double) * n * n);
