@@ -89,7 +89,7 @@ def main():
     ap.add_argument('--batch', type=int, default=4096, help='scenario instances per GPU')
     ap.add_argument('--agents', type=int, default=8)
     ap.add_argument('--horizon', type=int, default=20)
-    ap.add_argument('--cpu-agents', type=int, default=4096, help='agent-steps of the CPU baseline sample (time-capped at 25 s)')
+    ap.add_argument('--cpu-agents', type=int, default=32768, help='agent-steps of the CPU baseline sample (time-capped at 25 s)')
     ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
 

@@ -141,6 +141,7 @@ extern "C" void mpcx_search_model_destroy(mpcx_search_model *m) {
 extern "C" int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, int32_t n_nodes, const double *nodes,
                                      const double *nodes_cs, double *nbr, double *cost, uint8_t *collide) {
     if (!ctx) return MPCX_E_INVALID;
+    if (n_nodes == 0) return MPCX_OK;
     if (!m || n_nodes < 0 || !nodes || !nbr || !cost || !collide)
         return mpcx_fail(ctx, MPCX_E_INVALID, "expand_batch: null pointer or negative node count");
     if (n_nodes == 0) return MPCX_OK;

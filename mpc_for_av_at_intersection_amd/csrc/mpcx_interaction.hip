@@ -412,6 +412,7 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
                                           const int32_t *obs_cnt, const int32_t *obs_skip,
                                           int32_t *traj_idx, int32_t *hit_idx, double *hit_xy, int32_t *cut_len) {
     if (!ctx) return MPCX_E_INVALID;
+    if (P == 0) return MPCX_OK;
     if (!ip || P < 0 || n_obs_pool < 0 || !state || !path_xyyaw || !path_cs || !path_off || !path_len || !obs_off ||
         !obs_cnt || !traj_idx || !hit_idx || !hit_xy || !cut_len || (n_obs_pool > 0 && !obs6))
         return mpcx_fail(ctx, MPCX_E_INVALID, "interaction_batch: null pointer or negative size");
@@ -447,6 +448,7 @@ extern "C" int32_t mpcx_moving_collision_batch(mpcx_ctx *ctx, const mpcx_interac
                                                const int32_t *obs_off, const int32_t *obs_cnt,
                                                int32_t *hit_idx, double *hit_xy) {
     if (!ctx) return MPCX_E_INVALID;
+    if (P == 0) return MPCX_OK;
     if (!ip || P < 0 || n_obs_pool < 0 || !ego_xyyaw || !ego_cs || !ego_off || !ego_len || !path_xyyaw || !path_cs ||
         !path_off || !path_len || !obs_off || !obs_cnt || !hit_idx || !hit_xy || (n_obs_pool > 0 && (!obs_xyyaw || !obs_cs)))
         return mpcx_fail(ctx, MPCX_E_INVALID, "moving_collision_batch: null pointer or negative size");

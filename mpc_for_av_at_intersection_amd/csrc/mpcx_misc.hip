@@ -113,6 +113,7 @@ extern "C" int32_t mpcx_selftest_wave_ops(mpcx_ctx *ctx, const double *in64, dou
 extern "C" int32_t mpcx_transform_batch(mpcx_ctx *ctx, int32_t n_items, int32_t max_pts, const double *nodes,
                                         const int32_t *pts_off, const int32_t *pts_cnt, const double *pts, double *out) {
     if (!ctx) return MPCX_E_INVALID;
+    if (n_items == 0) return MPCX_OK;
     if (n_items < 0 || max_pts < 1 || !nodes || !pts_off || !pts_cnt || !pts || !out)
         return mpcx_fail(ctx, MPCX_E_INVALID, "transform_batch: null pointer or bad size");
     if (n_items == 0) return MPCX_OK;
@@ -125,6 +126,7 @@ extern "C" int32_t mpcx_transform_batch(mpcx_ctx *ctx, int32_t n_items, int32_t 
 extern "C" int32_t mpcx_cutoff_index_batch(mpcx_ctx *ctx, int32_t P, const double *pts, const int32_t *off,
                                            const int32_t *len, const double *xy, double radius, int32_t *out) {
     if (!ctx) return MPCX_E_INVALID;
+    if (P == 0) return MPCX_OK;
     if (P < 0 || !pts || !off || !len || !xy || !out) return mpcx_fail(ctx, MPCX_E_INVALID, "cutoff_index_batch: null pointer");
     if (P == 0) return MPCX_OK;
     mpcx::CutArgs a{P, pts, off, len, xy, radius, out};
@@ -135,6 +137,7 @@ extern "C" int32_t mpcx_cutoff_index_batch(mpcx_ctx *ctx, int32_t P, const doubl
 extern "C" int32_t mpcx_predict_obstacles_batch(mpcx_ctx *ctx, int32_t n, int32_t steps, double dt, double L,
                                                 const double *obs6, double *out_xyyaw) {
     if (!ctx) return MPCX_E_INVALID;
+    if (n == 0) return MPCX_OK;
     if (n < 0 || steps < 1 || !(dt > 0) || !(L > 0) || !obs6 || !out_xyyaw)
         return mpcx_fail(ctx, MPCX_E_INVALID, "predict_obstacles_batch: null pointer or bad size");
     if (n == 0) return MPCX_OK;

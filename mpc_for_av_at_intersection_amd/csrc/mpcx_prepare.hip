@@ -124,6 +124,7 @@ extern "C" int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double
                                           const int32_t *path_len, double dl, int32_t *target_ind, double *xref, uint8_t *reaches_end, double *xbar) {
     if (!ctx) return MPCX_E_INVALID;
     if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");
+    if (B == 0) return MPCX_OK;       // empty batch: nothing to do (zero-size tensors have null data pointers)
     if (B < 0 || !state || !path_xyyaw || !path_off || !path_len || !target_ind || !xref || !reaches_end || !xbar || !(dl > 0))
         return mpcx_fail(ctx, MPCX_E_INVALID, "mpc_prepare_batch: null pointer, negative batch or dl <= 0");
     if (B == 0) return MPCX_OK;
@@ -138,6 +139,7 @@ extern "C" int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state
                                          const int32_t *status, double *applied) {
     if (!ctx) return MPCX_E_INVALID;
     if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");
+    if (B == 0) return MPCX_OK;       // empty batch: nothing to do (zero-size tensors have null data pointers)
     if (B < 0 || !state || !u || !applied) return mpcx_fail(ctx, MPCX_E_INVALID, "plant_step_batch: null pointer");
     if (B == 0) return MPCX_OK;
     mpcx::PlantArgs pa{ctx->mpc, B, state, u, status, applied};

@@ -506,7 +506,18 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         rat = fmax(fmax(-ds0 * is0, -dl0 * il0), fmax(-ds1 * is1, -dl1 * il1));
         rat = fmax(rat, fmax(fmax(-ds2 * is2, -dl2 * il2), fmax(-ds3 * is3, -dl3 * il3)));
         rat = wave_max_dpp(rat);
-        const double alpha = (0.995 < rat) ? 0.995 * frcp(rat) : 1.0;     // min(1, 0.995/rat)
+        double alpha = (0.995 < rat) ? 0.995 * frcp(rat) : 1.0;           // min(1, 0.995/rat)
+        // centrality safeguard (wide neighbourhood): shorten the step until min_i s_i*lam_i >= 1e-3 * mu at the new point;
+        // plain Mehrotra otherwise cycles on poorly centred iterates (mu oscillates, residuals -> 0)
+        for (int tr = 0; tr < 6; tr++) {
+            const double q0 = (s0 + alpha * ds0) * (l0 + alpha * dl0), q1 = (s1 + alpha * ds1) * (l1 + alpha * dl1);
+            const double q2 = (s2 + alpha * ds2) * (l2 + alpha * dl2), q3 = (s3 + alpha * ds3) * (l3 + alpha * dl3);
+            const double big = 1e300;
+            const double pmin = -wave_max_dpp(-fmin(fmin(val01 ? q0 : big, val01 ? q1 : big), fmin(val23 ? q2 : big, val23 ? q3 : big)));
+            const double psum = wave_sum_dpp(m01 * (q0 + q1) + m23 * (q2 + q3));
+            if (pmin >= 1e-3 * (psum * minv)) break;
+            alpha *= 0.7;
+        }
         u += alpha * du;
         s0 += alpha * ds0; s1 += alpha * ds1; s2 += alpha * ds2; s3 += alpha * ds3;
         l0 += alpha * dl0; l1 += alpha * dl1; l2 += alpha * dl2; l3 += alpha * dl3;
@@ -560,6 +571,7 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
                                        double *x_out, double *u_out, int32_t *status, int32_t *iters, double *kkt) {
     if (!ctx) return MPCX_E_INVALID;
     if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");
+    if (B == 0) return MPCX_OK;       // empty batch: nothing to do (zero-size tensors have null data pointers)
     if (B < 0 || !x0 || !xref || !xbar || !reaches_end || !x_out || !u_out || !status || !iters || !kkt)
         return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: null pointer or negative batch");
     if (B == 0) return MPCX_OK;

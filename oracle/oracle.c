@@ -357,6 +357,18 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
             if (dl[i] < 0 && -lam[i] / dl[i] < amax) amax = -lam[i] / dl[i];
         }
         alpha = 0.995 * amax; if (alpha > 1.0) alpha = 1.0;
+        /* centrality safeguard (wide neighbourhood): shorten the step until min_i s_i*lam_i >= 1e-3 * mu at the new point;
+         * plain Mehrotra otherwise cycles on poorly centred iterates (mu oscillates, residuals -> 0) */
+        for (int tr = 0; tr < 6; tr++) {
+            double pmin = 1e300, psum = 0.0;
+            for (int i = 0; i < m; i++) {
+                double pr = (s[i] + alpha * ds[i]) * (lam[i] + alpha * dl[i]);
+                if (pr < pmin) pmin = pr;
+                psum += pr;
+            }
+            if (pmin >= 1e-3 * (psum / m)) break;
+            alpha *= 0.7;
+        }
         for (int k = 0; k < n; k++) u[k] += alpha * du[k];
         for (int i = 0; i < m; i++) { s[i] += alpha * ds[i]; lam[i] += alpha * dl[i]; }
     }

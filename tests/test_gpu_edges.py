@@ -1,0 +1,117 @@
+"""GPU edge cases of the C ABI: empty batches, invalid arguments, horizons that use the padded / largest kernel
+instantiations, degenerate paths, no obstacles, size limits."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from mpc_for_av_at_intersection_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _random_problems(T, n, seed):
+    """synthetic but realistic pre-QP tensors: a path window + a rollout of random controls (oracle builds them)"""
+    from oracle import oracle_py as orc
+    rng = np.random.default_rng(seed)
+    full = H.smoothed_path(1, 1)
+    dl = float(np.linalg.norm(full[0, :2] - full[1, :2]))
+    p = orc.MpcParams(T=T)
+    out = []
+    for k in range(n):
+        i0 = int(rng.integers(0, len(full) - 10))
+        cut = len(full) if k % 2 else min(len(full), i0 + int(rng.integers(5, 200)))
+        st = np.array([full[i0, 0] + rng.normal(0, .3), full[i0, 1] + rng.normal(0, .3), rng.uniform(0, 8.3), full[i0, 2] + rng.normal(0, .05)])
+        xref, s, re = orc.calc_ref_trajectory(p, st, full[:cut, 0], full[:cut, 1], full[:cut, 2], dl, max(0, i0 - 1))
+        oa = rng.uniform(-3, 2, T); od = rng.uniform(-.5, .5, T)
+        out.append((st, xref, orc.predict_motion(p, st, oa, od), re, np.stack([oa, od])))
+    return p, out
+
+
+@pytest.mark.parametrize('T', [1, 2, 5, 11, 16, 21, 27, 32])
+def test_qp_all_horizons_vs_oracle(ctx, T):
+    """T=1..10 -> qp_kernel<10> with padding unknowns, 11..13 -> <13>, 14..20 -> <20>, 21..32 -> <32> (64 unknowns)"""
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams
+    from oracle import oracle_py as orc
+    p, probs = _random_problems(T, 24, seed=T)
+    ctx.set_mpc_params(MpcParams(T=T))
+    st = np.array([q[0] for q in probs]); xref = np.array([q[1] for q in probs]); xbar = np.array([q[2] for q in probs])
+    re = np.array([q[3] for q in probs]); uw = np.array([q[4] for q in probs])
+    out = ctx.qp_solve(ctx.f64(st), ctx.f64(xref), ctx.f64(xbar), ctx.u8(re), ctx.f64(uw))
+    ctx.synchronize()
+    u = out['u'].cpu().numpy(); x = out['x'].cpu().numpy(); status = out['status'].cpu().numpy()
+    worst = 0.0
+    for k in range(len(probs)):
+        o = orc.qp_solve(p, st[k], xref[k], xbar[k], re[k], uw[k])
+        assert o.status == status[k]
+        if o.status == 0:
+            worst = max(worst, np.abs(o.u - u[k]).max(), np.abs(o.x - x[k]).max())
+    assert (status == 0).all() and worst < 1e-6, (status, worst)
+
+
+def test_empty_batches_and_invalid_arguments(ctx):
+    from mpc_for_av_at_intersection_amd.runtime import InteractionParams, MpcParams, MpcxError
+    ctx.set_mpc_params(MpcParams(T=13))
+    f = torch.float64
+    z = lambda *s, dt=f: torch.zeros(s, dtype=dt, device=ctx.device)
+    out = ctx.qp_solve(z(0, 4), z(0, 4, 14), z(0, 4, 14), z(0, 14, dt=torch.uint8))            # B = 0: no launch, no error
+    assert out['u'].shape == (0, 2, 13)
+    ctx.prepare(z(0, 4), None, z(5, 3), z(0, dt=torch.int32), z(0, dt=torch.int32), 0.1, z(0, dt=torch.int32))
+    with pytest.raises(MpcxError):
+        ctx.set_mpc_params(MpcParams(T=33))                                                     # beyond MPCX_T_MAX
+    with pytest.raises(MpcxError):
+        ctx.set_mpc_params(MpcParams(T=0))
+    with pytest.raises(MpcxError):
+        ctx.qp_solve(z(2, 4), z(2, 4, 13), z(2, 4, 14), z(2, 14, dt=torch.uint8))               # wrong shape caught on the host
+    lib = ctx.lib
+    rc = lib.mpcx_qp_solve_batch(ctx._ctx, 1, None, None, None, None, None, None, None, None, None, None)
+    assert rc == -1 and b'null' in lib.mpcx_last_error(ctx._ctx)                                # MPCX_E_INVALID from the C side
+    assert lib.mpcx_set_mpc_params(ctx._ctx, None) == -1
+    with pytest.raises(MpcxError):
+        ctx.search_model([np.zeros((600, 3))], np.zeros((1, 3)), np.zeros(1), np.zeros((4, 3)), np.array([0, 4]))  # > 512 template points
+    with pytest.raises(MpcxError):
+        ctx.prepare(z(1, 4), None, z(5, 3), z(1, dt=torch.int32), z(1, dt=torch.int32) + 5, 0.0, z(1, dt=torch.int32))   # dl <= 0
+
+
+def test_degenerate_paths_and_no_obstacles(ctx):
+    from mpc_for_av_at_intersection_amd.runtime import InteractionParams, MpcParams
+    from oracle import oracle_py as orc
+    T = 13
+    ctx.set_mpc_params(MpcParams(T=T))
+    po = orc.MpcParams(T=T)
+    full = H.smoothed_path(2, 1)
+    dl = float(np.linalg.norm(full[0, :2] - full[1, :2]))
+    # paths of length 1, 2, 3 and a start index beyond the (cut) path: trajectories.py:122-126 and mpc.py:100
+    cases = [(1, 0), (2, 0), (3, 0), (3, 2), (50, 60), (len(full), len(full) - 1)]
+    st = np.array([[full[0, 0], full[0, 1], 1.0, full[0, 2]]] * len(cases))
+    tind = ctx.i32([c[1] for c in cases])
+    pre = ctx.prepare(ctx.f64(st), None, ctx.f64(full), ctx.i32([0] * len(cases)), ctx.i32([c[0] for c in cases]), dl, tind)
+    ctx.synchronize()
+    for k, (n, s0) in enumerate(cases):
+        xref, s, re = orc.calc_ref_trajectory(po, st[k], full[:n, 0], full[:n, 1], full[:n, 2], dl, s0)
+        assert int(tind.cpu()[k]) == s
+        assert np.array_equal(pre['xref'].cpu().numpy()[k], xref) and np.array_equal(pre['reaches_end'].cpu().numpy()[k], re)
+    # interaction with an empty obstacle pool -> None (collision_avoidance.py:69-70), path untouched
+    car = H.car()
+    ip = InteractionParams(L=car['L'], radius=car['radius'], circle_centers=np.array(car['circle_centers']).ravel())
+    cs = np.column_stack([np.cos(full[:, 2]), np.sin(full[:, 2])])
+    ti = ctx.i32([3, 10])
+    out = ctx.interaction(ip, ctx.f64(st[:2]), ctx.f64(full), ctx.f64(cs), ctx.i32([0, 0]), ctx.i32([len(full)] * 2), None,
+                          None, ctx.i32([0, 0]), ctx.i32([0, 0]), None, ti)
+    ctx.synchronize()
+    assert (out['hit_idx'].cpu().numpy() == -1).all() and (out['cut_len'].cpu().numpy() == len(full)).all()
+    # more obstacles than MPCX_MAX_OBS -> per-problem limit code -2, not a crash
+    pool = np.tile([[100.0, 100.0, 0.0, 0.0, 0.0, 0.0]], (20, 1))
+    out = ctx.interaction(ip, ctx.f64(st[:1]), ctx.f64(full), ctx.f64(cs), ctx.i32([0]), ctx.i32([len(full)]), None,
+                          ctx.f64(pool), ctx.i32([0]), ctx.i32([20]), None, ctx.i32([0]))
+    ctx.synchronize()
+    assert int(out['hit_idx'].cpu()[0]) == -2
