@@ -113,3 +113,35 @@ def test_expansion_one_million_nodes(ctx):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print('expand_kernel: 2^20 nodes x %d primitives in %.3f ms = %.1f M nodes/s' % (model.n_prim, ms, n / ms / 1e3))
+
+
+def test_config2_256_independent_instances_closed_loop(ctx):
+    """BASELINE configs[1]: batch = 256 independent single-ego instances, N = 20, float64 -- 12 closed-loop steps, every
+    agent replayed step by step on the oracle from the device state of the previous step."""
+    from mpc_for_av_at_intersection_amd.batch import stock_routes, synthetic_batch
+    from oracle import oracle_py as orc
+    routes, dl, cd = stock_routes(ctx)
+    B, T = 256, 20
+    sim = synthetic_batch(ctx, B=B, A=1, T=T, seed=11, routes=routes, dl=dl, cd=cd)
+    tab = sim.path.cpu().numpy(); off = sim.path_off.cpu().numpy(); ln = sim.path_len.cpu().numpy()
+    po = orc.MpcParams(T=T, L=sim.params.L)
+    centers = np.asarray(sim.ip.circle_centers).reshape(2, 2)
+    worst = 0.0
+    before = sim.snapshot()
+    for step in range(12):
+        sim.step()
+        after = sim.snapshot()
+        assert (after['status'] == 0).all()
+        for q in range(0, B, 4 if step else 1):          # all agents on the first step, every 4th afterwards
+            r = orc.agent_step(po, tab[off[q]:off[q] + ln[q]], sim.dl, before['state'][q], np.zeros((0, 6)), int(before['traj_idx'][q]),
+                               int(before['prev_cut'][q]), int(before['target_ind'][q]), before['u'][q] if step else None,
+                               centers, sim.ip.radius, sim.ip.cutoff_margin)
+            assert r['traj_idx'] == after['traj_idx'][q] and r['target_ind'] == after['target_ind'][q] and r['cut'] == ln[q]
+            assert np.array_equal(r['xref'], after['xref'][q]) and np.array_equal(r['re'], after['reaches_end'][q])
+            worst = max(worst, np.abs(r['sol'].u - after['u'][q]).max(), np.abs(r['xbar'] - after['xbar'][q]).max())
+            # plant: the oracle's Euler step from the same control reproduces the device state
+            nxt = orc.plant_step(po, before['state'][q], r['sol'].u[0, 0], r['sol'].u[1, 0])
+            assert np.abs(nxt - after['state'][q]).max() < 1e-9
+        before = after
+    assert worst < 2e-7, worst
+    assert (after['state'][:, 2] > 1.0).all()            # everybody got going
