@@ -169,6 +169,8 @@ int32_t mpcx_predict_obstacles_batch(mpcx_ctx *ctx, int32_t n, int32_t steps, do
 /* ---- self-test of the wave-level DPP helpers the kernels rely on (scans, shifts, reductions, reciprocal):
  * in64 = 64 doubles, out322 = results, layout documented at selftest_kernel in csrc/mpcx_misc.hip. */
 int32_t mpcx_selftest_wave_ops(mpcx_ctx *ctx, const double *in64, double *out322);
+/* f64 MFMA lane maps (v_mfma_f64_16x16x4) used by the Hessian build: D(16x16) = A(16x4, row-major) * B(4x16, row-major) */
+int32_t mpcx_selftest_mfma(mpcx_ctx *ctx, const double *A64, const double *B64, double *D256);
 
 /* ---- plant: lib/simulation.py:35-47 `Simulation.step` on B states with the first control of each solution;
  * failed instances (status != 0) get (previous steer, MAX_DECEL) as MPC.step does (mpc.py:294-297) and their row of

@@ -29,7 +29,7 @@ class InteractionParamsC(C.Structure):
 EXPORTS = ['mpcx_create', 'mpcx_destroy', 'mpcx_last_error', 'mpcx_version', 'mpcx_set_mpc_params',
            'mpcx_qp_solve_batch', 'mpcx_mpc_prepare_batch', 'mpcx_search_model_create', 'mpcx_search_model_destroy',
            'mpcx_expand_batch', 'mpcx_interaction_batch', 'mpcx_moving_collision_batch', 'mpcx_plant_step_batch',
-           'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch', 'mpcx_selftest_wave_ops']
+           'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch', 'mpcx_selftest_wave_ops', 'mpcx_selftest_mfma']
 
 
 def load():
@@ -67,5 +67,6 @@ def load():
     lib.mpcx_predict_obstacles_batch.restype = i32
     lib.mpcx_predict_obstacles_batch.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
     lib.mpcx_selftest_wave_ops.restype = i32; lib.mpcx_selftest_wave_ops.argtypes = [vp, vp, vp]
+    lib.mpcx_selftest_mfma.restype = i32; lib.mpcx_selftest_mfma.argtypes = [vp, vp, vp, vp]
     _lib = lib
     return lib

@@ -35,6 +35,11 @@ mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
     c->stream = (hipStream_t)hip_stream;
     c->have_mpc = false;
     c->pred = nullptr;
+    c->ticket = nullptr;
+    {
+        hipDeviceProp_t prop;
+        c->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
     c->pred_cap = 0;
     c->err[0] = 0;
     return c;
@@ -43,6 +48,7 @@ mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
 void mpcx_destroy(mpcx_ctx *ctx) {
     if (!ctx) return;
     if (ctx->pred) (void)hipFree(ctx->pred);
+    if (ctx->ticket) (void)hipFree(ctx->ticket);
     delete ctx;
 }
 

@@ -9,6 +9,8 @@ struct mpcx_ctx {
     hipStream_t stream;
     mpcx_mpc_params mpc;
     bool have_mpc;
+    int32_t *ticket;     // device word: work-queue head of the persistent QP kernel
+    int n_cu;            // compute units of the device
     double *pred;        // scratch: predicted obstacle disc centres [NOBS][steps][2 discs][2]
     size_t pred_cap;     // capacity of pred in doubles
     char err[256];

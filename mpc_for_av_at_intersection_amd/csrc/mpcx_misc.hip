@@ -102,7 +102,25 @@ __global__ __launch_bounds__(64) void selftest_kernel(const double *in, double *
     out[258 + lane] = frcp1(v);
 }
 
+// self-test of the f64 MFMA lane maps the Hessian build relies on: D = A(16x4) * B(4x16), A and B given row-major
+typedef double double4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void selftest_mfma_kernel(const double *A, const double *B, double *D) {
+    const int l = threadIdx.x;
+    const double a = A[(l & 15) * 4 + (l >> 4)];        // A[i = l&15][k = l>>4]
+    const double b = B[(l >> 4) * 16 + (l & 15)];       // B[k = l>>4][j = l&15]
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];   // D[row = (l>>4) + 4r][col = l&15]
+}
+
 }  // namespace mpcx
+
+extern "C" int32_t mpcx_selftest_mfma(mpcx_ctx *ctx, const double *A64, const double *B64, double *D256) {
+    if (!ctx || !A64 || !B64 || !D256) return MPCX_E_INVALID;
+    hipLaunchKernelGGL(mpcx::selftest_mfma_kernel, dim3(1), dim3(64), 0, ctx->stream, A64, B64, D256);
+    return mpcx_check_launch(ctx, "selftest_mfma_kernel");
+}
 
 extern "C" int32_t mpcx_selftest_wave_ops(mpcx_ctx *ctx, const double *in64, double *out322) {
     if (!ctx || !in64 || !out322) return MPCX_E_INVALID;

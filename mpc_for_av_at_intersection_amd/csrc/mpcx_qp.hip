@@ -40,9 +40,12 @@
 
 namespace mpcx {
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 struct QpArgs {
     mpcx_mpc_params p;
     int B;
+    int32_t *ticket;      // work queue head (zeroed before the launch): wavefronts draw QP indices until B is exhausted
     int has_warm;         // u_warm != NULL (tested on the host: a device-side null test of a kernel-argument pointer trips a
                           // gfx950 instruction-selection bug in some register-allocation outcomes)
     const double *x0, *xref, *xbar, *u_warm;
@@ -60,7 +63,7 @@ struct QpShared {
     double beta[32];        // dt * vbar_k / L
     double wt[33][6];       // per-t cost weights: wxx, wxy, wyy, wv, wyaw (padded to 48 B so rows stay 16-B aligned)
     double we[NT + 1][4];   // W_t * (free response - reference)
-    double gb[WAVE][4];     // W_t * sensitivity of every unknown at the current t (Hessian build broadcast)
+    double wf[33][4][4];    // per-t factor rows F_t (F_t'F_t = W_t): [t][component][qx, qy, qv, qyaw]
     double cb[2][WAVE];     // factorisation column broadcast (double buffered)
     double ub[WAVE];        // current iterate broadcast
     double sb[WAVE];        // speed-row suffix sums broadcast
@@ -133,8 +136,13 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     constexpr int PRE = (N - 1 < MPCX_PRE) ? N - 1 : MPCX_PRE;   // column entries prefetched one column ahead in the factorisation
     constexpr int BCH = MPCX_BCH;          // same, stage pairs in the Hessian build (8 doubles each)
     __shared__ QpShared<NT> sh;
-    const int b = blockIdx.x;
     const int lane = threadIdx.x;
+  for (int guard = 0; guard <= a.B; guard++) {      // every wavefront leaves after at most B+1 tickets (bounded by construction)
+    int b = 0;
+    if (lane == 0) b = atomicAdd(a.ticket, 1);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= a.B) break;
+    lds_sync();                       // the previous problem's LDS reads are done before this one overwrites the tables
     const mpcx_mpc_params &P = a.p;
     const int T = P.T, W = T + 1;
     const double dt = P.dt;
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         if (dyn) sh.beta[t] = m * (dt * vb / P.L);
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            double v = scan_up(vals[r], lane);           // lanes >= 32 contribute zeros
+            double v = scan_up32(vals[r]);               // DPP scan over lanes 0..31 (lanes >= 32 carry zeros)
             if (dyn && t < NT) sh.pre[r][t + 1] = v;
             if (lane == 0) sh.pre[r][0] = 0.0;
         }
@@ -184,6 +192,14 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
             if (ended) { wxx = P.Qf[0]; wxy = 0.0; wyy = P.Qf[1]; wv = P.Qf[2]; wp = P.Qf[3]; }
             const double mm = on ? 1.0 : 0.0;
             sh.wt[t][0] = mm * wxx; sh.wt[t][1] = mm * wxy; sh.wt[t][2] = mm * wyy; sh.wt[t][3] = mm * wv; sh.wt[t][4] = mm * wp;
+            // factor rows: along-track, cross-track, speed, yaw (terminal stages: axis-aligned sqrt(Qf))
+            const double ra = ended ? sqrt(P.Qf[0]) : sqrt(P.w_para), rc = ended ? sqrt(P.Qf[1]) : sqrt(P.w_perp);
+            const double rv = mm * sqrt(wv), rp = mm * sqrt(wp);
+            const double cc = ended ? 1.0 : c, ss = ended ? 0.0 : s;
+            sh.wf[t][0][0] = mm * ra * cc;  sh.wf[t][0][1] = mm * ra * ss;  sh.wf[t][0][2] = 0.0; sh.wf[t][0][3] = 0.0;
+            sh.wf[t][1][0] = -mm * rc * ss; sh.wf[t][1][1] = mm * rc * cc;  sh.wf[t][1][2] = 0.0; sh.wf[t][1][3] = 0.0;
+            sh.wf[t][2][0] = 0.0; sh.wf[t][2][1] = 0.0; sh.wf[t][2][2] = rv;  sh.wf[t][2][3] = 0.0;
+            sh.wf[t][3][0] = 0.0; sh.wf[t][3][1] = 0.0; sh.wf[t][3][2] = 0.0; sh.wf[t][3][3] = rp;
         }
         if (lane == 0) { sh.wt[0][0] = 0; sh.wt[0][1] = 0; sh.wt[0][2] = 0; sh.wt[0][3] = 0; sh.wt[0][4] = 0; }
     }
@@ -204,10 +220,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     }
     lds_sync();
 
-    // ---------------------------------------------------------------- condensed Hessian row + gradient
-    double R[N];
-#pragma unroll
-    for (int j = 0; j < N; j++) R[j] = 0.0;
+    // ---------------------------------------------------------------- gradient (lane = own unknown, plain VALU)
     double g = 0.0;
     {
         const double coef = real ? (kind ? sh.beta[kc] : dt) : 0.0;
@@ -219,36 +232,73 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
             const double act = (real && (t >= k + 1)) ? 1.0 : 0.0;     // stages t > T carry zero weights
             const double ca = act * coef;
             const double gx = ca * (sh.pre[rx][t] - bx0), gy = ca * (sh.pre[ry][t] - by0), gv = act * cv, gp = act * cp;
-            const double wxx = sh.wt[t][0], wxy = sh.wt[t][1], wyy = sh.wt[t][2], wv = sh.wt[t][3], wp = sh.wt[t][4];
-            sh.gb[lane][0] = wxx * gx + wxy * gy;
-            sh.gb[lane][1] = wxy * gx + wyy * gy;
-            sh.gb[lane][2] = wv * gv;
-            sh.gb[lane][3] = wp * gp;
             g += gx * sh.we[t][0] + gy * sh.we[t][1] + gv * sh.we[t][2] + gp * sh.we[t][3];
-            lds_sync();
-            // only unknowns of stages < t have a non-zero sensitivity at time t
-            {
-#pragma unroll
-                for (int k0 = 0; k0 < t; k0 += BCH) {
-                    const int k1 = (k0 + BCH < t) ? k0 + BCH : t;
-                    double w4[2 * NT][4];
-#pragma unroll
-                    for (int kk = k0; kk < k1; kk++) {
-#pragma unroll
-                        for (int c = 0; c < 4; c++) { w4[kk][c] = sh.gb[kk][c]; w4[NT + kk][c] = sh.gb[NT + kk][c]; }
-                    }
-#pragma unroll
-                    for (int kk = k0; kk < k1; kk++) {
-                        R[kk] += gx * w4[kk][0] + gy * w4[kk][1] + gv * w4[kk][2] + gp * w4[kk][3];
-                        R[NT + kk] += gx * w4[NT + kk][0] + gy * w4[NT + kk][1] + gv * w4[NT + kk][2] + gp * w4[NT + kk][3];
-                    }
-#pragma unroll
-                    for (int kk = k0; kk < k1; kk++) { pin(R[kk]); pin(R[NT + kk]); }
-                }
-            }
-            lds_sync();
         }
         g *= 2.0;
+    }
+    // ---------------------------------------------------------------- condensed Hessian H = 2 * sum_t G_t' G_t  on the
+    // matrix cores.  G_t (4 x n) = F_t * [sensitivities of every unknown at stage t], F_t'F_t = W_t (rotation into the path
+    // frame scaled by sqrt of the along-/cross-track weights, or sqrt(Qf) on the terminal stages).  One v_mfma_f64_16x16x4
+    // per 16x16 output tile and stage: lane l supplies component c = l>>4 of unknown 16*tile + (l&15) as both the A and the
+    // B operand, the 4-deep contraction runs over the state components.  (FP64 MFMA and FP64 VALU peak at the same rate on
+    // MI355X; the gain is that 1024 FMAs retire per issued instruction and the VALU stays free for the operands.)
+    {
+        constexpr int NTILE = (N + 15) / 16;
+        const int cmp = lane >> 4;                                   // state component carried by this lane
+        double4_t acc[NTILE][NTILE];
+#pragma unroll
+        for (int I = 0; I < NTILE; I++)
+#pragma unroll
+            for (int J = 0; J <= I; J++) acc[I][J] = double4_t{0.0, 0.0, 0.0, 0.0};
+        double tc[NTILE], tb0x[NTILE], tb0y[NTILE];                  // per tile: coefficient and prefix offsets of "my" unknown
+        int tk[NTILE], trx[NTILE];
+        bool tkind[NTILE], treal[NTILE];
+#pragma unroll
+        for (int I = 0; I < NTILE; I++) {
+            const int var = 16 * I + (lane & 15);
+            tkind[I] = var >= NT;
+            tk[I] = var - (tkind[I] ? NT : 0);
+            treal[I] = (var < N) && (tk[I] < T);
+            const int kcl = treal[I] ? tk[I] : 0;
+            tc[I] = treal[I] ? (tkind[I] ? sh.beta[kcl] : dt) : 0.0;
+            trx[I] = tkind[I] ? 2 : 0;
+            tb0x[I] = sh.pre[trx[I]][kcl + 1];
+            tb0y[I] = sh.pre[trx[I] + 1][kcl + 1];
+        }
+#pragma unroll
+        for (int t = 1; t <= NT; t++) {
+            const double qx = sh.wf[t][cmp][0], qy = sh.wf[t][cmp][1], qv = sh.wf[t][cmp][2], qp = sh.wf[t][cmp][3];
+            double gt[NTILE];
+#pragma unroll
+            for (int I = 0; I < NTILE; I++) {
+                const bool on = treal[I] && (t >= tk[I] + 1);
+                const double dx = sh.pre[trx[I]][t] - tb0x[I], dy = sh.pre[trx[I] + 1][t] - tb0y[I];
+                const double lin = qx * dx + qy * dy + (tkind[I] ? qp : qv);
+                gt[I] = on ? tc[I] * lin : 0.0;
+            }
+#pragma unroll
+            for (int I = 0; I < NTILE; I++)
+#pragma unroll
+                for (int J = 0; J <= I; J++) acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(gt[I], gt[J], acc[I][J], 0, 0, 0);
+        }
+        // C/D layout: register r of lane l is element (row = (l>>4) + 4r, col = l&15) of the tile.  H is symmetric: element
+        // (row, col) is stored at both [row*N + col] and [col*N + row] of the column-major LDS copy.
+#pragma unroll
+        for (int I = 0; I < NTILE; I++)
+#pragma unroll
+            for (int J = 0; J <= I; J++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * I + cmp + 4 * r, col = 16 * J + (lane & 15);
+                    const double v = 2.0 * acc[I][J][r];
+                    if (row < N && col < N) {
+                        sh.H[row * N + col] = v;
+                        if (I != J) sh.H[col * N + row] = v;
+                    }
+                }
+    }
+    lds_sync();
+    {
         // input cost (mpc.py:177-180) and input-rate cost (mpc.py:182-183); objective has no 1/2 => H = 2*(...)
         const double rr = re[kc] ? P.R_end[kind] : P.R[kind];
         const double rdc = P.Rd[kind];
@@ -256,17 +306,10 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         const double dg = real ? (2.0 * rr + 2.0 * rdc * nb) : 1.0;     // padding unknowns: identity row
         const double off_lo = (real && k >= 1) ? -2.0 * rdc : 0.0;
         const double off_hi = (real && k + 1 < T) ? -2.0 * rdc : 0.0;
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            double v = 2.0 * R[j];
-            v += (lane == j) ? dg : 0.0;
-            v += (lane == j + 1) ? off_lo : 0.0;
-            v += (lane == j - 1) ? off_hi : 0.0;
-            R[j] = v;
-        }
         if (inrow) {
-#pragma unroll
-            for (int j = 0; j < N; j++) sh.H[j * N + lane] = R[j];
+            sh.H[lane * N + lane] += dg;
+            if (lane + 1 < N) sh.H[(lane + 1) * N + lane] += off_hi;
+            if (lane >= 1) sh.H[(lane - 1) * N + lane] += off_lo;
         }
     }
     lds_sync();
@@ -308,6 +351,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         return (w0 - w1) + (kind == 0 ? dt * sa : (qp - q));
     };
 
+    double R[N];            // row `lane` of M, then of its factor (see ldl_solve)
     double s0, s1, s2, s3, l0 = 1.0, l1 = 1.0, l2 = 1.0, l3 = 1.0;
     {
         const double e2 = second_rows(u);
@@ -557,11 +601,12 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         a.iters[b] = it;
         a.kkt[4 * b + 0] = res_d; a.kkt[4 * b + 1] = res_p; a.kkt[4 * b + 2] = mu; a.kkt[4 * b + 3] = 0.0;
     }
+  }   // work loop
 }
 
 template <int NT>
-static void launch_qp(const QpArgs &a, hipStream_t st) {
-    hipLaunchKernelGGL(qp_kernel<NT>, dim3(a.B), dim3(64), 0, st, a);
+static void launch_qp(const QpArgs &a, hipStream_t st, int grid) {
+    hipLaunchKernelGGL(qp_kernel<NT>, dim3(grid), dim3(64), 0, st, a);
 }
 
 }  // namespace mpcx
@@ -575,11 +620,17 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     if (B < 0 || !x0 || !xref || !xbar || !reaches_end || !x_out || !u_out || !status || !iters || !kkt)
         return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: null pointer or negative batch");
     if (B == 0) return MPCX_OK;
-    mpcx::QpArgs a{ctx->mpc, B, u_warm != nullptr, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters};
+    if (!ctx->ticket && hipMalloc((void **)&ctx->ticket, sizeof(int32_t)) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: cannot allocate the work-queue word");
+    if (hipMemsetAsync(ctx->ticket, 0, sizeof(int32_t), ctx->stream) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipMemsetAsync failed");
+    // persistent wavefronts: one per SIMD slot the kernel can occupy (1 wave/SIMD, 4 SIMDs/CU), never more than B
+    const int grid = B < ctx->n_cu * 4 ? B : ctx->n_cu * 4;
+    mpcx::QpArgs a{ctx->mpc, B, ctx->ticket, u_warm != nullptr, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters};
     const int T = ctx->mpc.T;
-    if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream);
-    else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream);
-    else if (T <= 20) mpcx::launch_qp<20>(a, ctx->stream);
-    else mpcx::launch_qp<32>(a, ctx->stream);
+    if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream, grid);
+    else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream, grid);
+    else if (T <= 20) mpcx::launch_qp<20>(a, ctx->stream, grid);
+    else mpcx::launch_qp<32>(a, ctx->stream, grid);
     return mpcx_check_launch(ctx, "qp_kernel");
 }

@@ -154,3 +154,15 @@ def test_wave_helpers_selftest(ctx):
     assert np.array_equal(o[193:256], v[:-1]) and o[192] == -1.0
     assert abs(o[256] - v.sum()) < 1e-12 and o[257] == v.max()
     assert np.abs(o[258:] * v - 1.0).max() < 1e-14
+
+
+def test_mfma_f64_lane_maps(ctx):
+    """v_mfma_f64_16x16x4 operand / result lane maps (asymmetric data, so a transposed map cannot pass)"""
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    A = rng.integers(-5, 6, (16, 4)).astype(np.float64); B = rng.integers(-5, 6, (4, 16)).astype(np.float64)
+    dA, dB = ctx.f64(A), ctx.f64(B)
+    D = torch.zeros((16, 16), dtype=torch.float64, device=ctx.device)
+    assert ctx.lib.mpcx_selftest_mfma(ctx._ctx, C.c_void_p(dA.data_ptr()), C.c_void_p(dB.data_ptr()), C.c_void_p(D.data_ptr())) == 0
+    ctx.synchronize()
+    assert np.array_equal(D.cpu().numpy(), A @ B)
