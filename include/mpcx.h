@@ -178,6 +178,37 @@ int32_t mpcx_selftest_mfma(mpcx_ctx *ctx, const double *A64, const double *B64, 
 int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state /*B,4 in-out*/, double *u /*B,2,T in-out*/,
                               const int32_t *status /*B or NULL*/, double *applied /*B,2 in-out: (steer, accel)*/);
 
+/* ---- the closed loop itself: scenarios/mpc_intersection.py:95-159 for P agents, n_steps times, with no host work
+ * between steps.  One step = [pool row q <- (x, y, v, yaw, accel, steer) of agent q, what MovingObstacle*.get()
+ * returns] -> mpcx_interaction_batch (prev_cut_len = the cut_len of the previous step; zero = none yet) ->
+ * mpcx_mpc_prepare_batch (path_len = cut_len, warm start = u_sol) -> mpcx_qp_solve_batch (warm start = u_sol, in
+ * place) -> mpcx_plant_step_batch.  Every agent is a moving obstacle for the agents whose obs_off/obs_cnt window
+ * covers it, so the pool has exactly P rows.  All pointers are device pointers owned by the caller; the buffers
+ * are the same ones the per-stage entry points take and hold the same values afterwards.
+ * use_graph != 0 captures one step into a hipGraph on the context's stream (which must then not be the null
+ * stream) and replays it n_steps times; the instantiated graph is cached in the context per descriptor. */
+typedef struct {
+    int32_t P, reserved;
+    double dl;
+    double *state /*P,4*/, *applied /*P,2: (steer, accel)*/, *obs6 /*P,6 scratch*/;
+    const double *path_xyyaw, *path_cs, *path_v /*or NULL*/;
+    const int32_t *path_off /*P*/, *path_len /*P*/, *obs_off /*P*/, *obs_cnt /*P*/, *obs_skip /*P or NULL*/;
+    int32_t *traj_idx /*P*/, *target_ind /*P*/, *hit_idx /*P*/, *cut_len /*P, zero-initialised*/;
+    double *hit_xy /*P,2*/, *xref /*P,4,T+1*/, *xbar /*P,4,T+1*/;
+    uint8_t *reaches_end /*P,T+1*/;
+    double *x_sol /*P,4,T+1*/, *u_sol /*P,2,T zero-initialised*/;
+    int32_t *status /*P*/, *iters /*P*/;
+    double *kkt /*P,4*/;
+} mpcx_closed_loop;
+int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *cl,
+                             int32_t n_steps, int32_t use_graph);
+
+/* ---- measurement hook: while enabled, every mpcx_qp_solve_batch launch (direct or through mpcx_closed_loop_run
+ * without a graph) is bracketed by a pair of HIP events on the context's stream.  mpcx_profile_qp_read waits for
+ * the recorded launches, returns their summed duration and count, and clears the record. */
+int32_t mpcx_profile_qp(mpcx_ctx *ctx, int32_t enable);
+int32_t mpcx_profile_qp_read(mpcx_ctx *ctx, double *total_ms, int32_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

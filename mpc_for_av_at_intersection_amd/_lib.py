@@ -26,10 +26,19 @@ class InteractionParamsC(C.Structure):
                 ('circle_centers', C.c_double * 4), ('max_accel', C.c_double), ('max_speed', C.c_double)]
 
 
+class ClosedLoopC(C.Structure):
+    """mirror of mpcx_closed_loop (include/mpcx.h); every pointer is a device address"""
+    _PTRS = ['state', 'applied', 'obs6', 'path_xyyaw', 'path_cs', 'path_v', 'path_off', 'path_len', 'obs_off', 'obs_cnt',
+             'obs_skip', 'traj_idx', 'target_ind', 'hit_idx', 'cut_len', 'hit_xy', 'xref', 'xbar', 'reaches_end',
+             'x_sol', 'u_sol', 'status', 'iters', 'kkt']
+    _fields_ = [('P', C.c_int32), ('reserved', C.c_int32), ('dl', C.c_double)] + [(n, C.c_void_p) for n in _PTRS]
+
+
 EXPORTS = ['mpcx_create', 'mpcx_destroy', 'mpcx_last_error', 'mpcx_version', 'mpcx_set_mpc_params',
            'mpcx_qp_solve_batch', 'mpcx_mpc_prepare_batch', 'mpcx_search_model_create', 'mpcx_search_model_destroy',
            'mpcx_expand_batch', 'mpcx_interaction_batch', 'mpcx_moving_collision_batch', 'mpcx_plant_step_batch',
-           'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch', 'mpcx_selftest_wave_ops', 'mpcx_selftest_mfma']
+           'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch', 'mpcx_selftest_wave_ops', 'mpcx_selftest_mfma',
+           'mpcx_closed_loop_run', 'mpcx_profile_qp', 'mpcx_profile_qp_read']
 
 
 def load():
@@ -68,5 +77,10 @@ def load():
     lib.mpcx_predict_obstacles_batch.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
     lib.mpcx_selftest_wave_ops.restype = i32; lib.mpcx_selftest_wave_ops.argtypes = [vp, vp, vp]
     lib.mpcx_selftest_mfma.restype = i32; lib.mpcx_selftest_mfma.argtypes = [vp, vp, vp, vp]
+    lib.mpcx_closed_loop_run.restype = i32
+    lib.mpcx_closed_loop_run.argtypes = [vp, C.POINTER(InteractionParamsC), C.POINTER(ClosedLoopC), i32, i32]
+    lib.mpcx_profile_qp.restype = i32; lib.mpcx_profile_qp.argtypes = [vp, i32]
+    lib.mpcx_profile_qp_read.restype = i32
+    lib.mpcx_profile_qp_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     _lib = lib
     return lib

@@ -5,14 +5,16 @@ One `step()` is the body of the reference's scenario loop (main/scenarios/mpc_in
 search and path cut (mpcx_interaction_batch), reference window + warm-start rollout (mpcx_mpc_prepare_batch), the
 QP (mpcx_qp_solve_batch) and the plant update (mpcx_plant_step_batch). Every other agent of the same instance plays
 the role of the reference's `moving_obstacles`: it is described by (x, y, v, yaw, a, steer) exactly like
-`MovingObstacle*.get()` (a, steer = the controls it applied last step). All state lives on the device; a step issues
-five launches and no host synchronisation.
+`MovingObstacle*.get()` (a, steer = the controls it applied last step). All state lives on the device.
+`run(n)` hands the whole loop to mpcx_closed_loop_run (n steps enqueued back to back, optionally as a replayed
+hipGraph); `step_staged()` drives the same kernels stage by stage through the per-stage entry points.
 """
 from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
 
+from . import _lib
 from .runtime import Context, InteractionParams, MpcParams
 
 
@@ -46,14 +48,14 @@ class IntersectionBatch:
         self.applied = torch.zeros((P, 2), dtype=torch.float64, device=dev)      # (steer, accel) of the last step
         self.traj_idx = ctx.i32(s)
         self.target_ind = ctx.i32(s)
-        self.prev_cut = torch.zeros(P, dtype=torch.int32, device=dev)            # 0 = no tmp_trajectory yet
         self.obs_off = ctx.i32(np.repeat(np.arange(self.B) * self.A, self.A))
         self.obs_cnt = torch.full((P,), self.A, dtype=torch.int32, device=dev)
         self.obs_skip = ctx.i32(np.arange(P))
         f = torch.float64
         self.obs6 = torch.zeros((P, 6), dtype=f, device=dev)
+        # cut_len doubles as "length of the previous tmp_trajectory" (0 = none yet) for the next step
         self.inter = dict(hit_idx=torch.empty(P, dtype=torch.int32, device=dev), hit_xy=torch.empty((P, 2), dtype=f, device=dev),
-                          cut_len=torch.empty(P, dtype=torch.int32, device=dev))
+                          cut_len=torch.zeros(P, dtype=torch.int32, device=dev))
         self.pre = dict(xref=torch.empty((P, 4, T + 1), dtype=f, device=dev),
                         reaches_end=torch.empty((P, T + 1), dtype=torch.uint8, device=dev),
                         xbar=torch.empty((P, 4, T + 1), dtype=f, device=dev))
@@ -61,8 +63,35 @@ class IntersectionBatch:
                         status=torch.zeros(P, dtype=torch.int32, device=dev), iters=torch.zeros(P, dtype=torch.int32, device=dev),
                         kkt=torch.zeros((P, 4), dtype=f, device=dev))
         self.steps_done = 0
+        self.path_v = None
+        self._desc = None
+
+    def _descriptor(self) -> '_lib.ClosedLoopC':
+        d = _lib.ClosedLoopC()
+        d.P, d.reserved, d.dl = self.P, 0, self.dl
+        bufs = dict(state=self.state, applied=self.applied, obs6=self.obs6, path_xyyaw=self.path, path_cs=self.path_cs,
+                    path_v=self.path_v, path_off=self.path_off, path_len=self.path_len, obs_off=self.obs_off,
+                    obs_cnt=self.obs_cnt, obs_skip=self.obs_skip, traj_idx=self.traj_idx, target_ind=self.target_ind,
+                    hit_idx=self.inter['hit_idx'], cut_len=self.inter['cut_len'], hit_xy=self.inter['hit_xy'],
+                    xref=self.pre['xref'], xbar=self.pre['xbar'], reaches_end=self.pre['reaches_end'],
+                    x_sol=self.sol['x'], u_sol=self.sol['u'], status=self.sol['status'], iters=self.sol['iters'],
+                    kkt=self.sol['kkt'])
+        for k, t in bufs.items():
+            setattr(d, k, None if t is None else t.data_ptr())
+        return d
+
+    def run(self, n_steps: int, graph: bool = False):
+        """n_steps of the closed loop with no host work in between (mpcx_closed_loop_run)."""
+        if self._desc is None:
+            self._desc = self._descriptor()
+        self.ctx.closed_loop_run(self.ip, self._desc, n_steps, graph)
+        self.steps_done += n_steps
 
     def step(self):
+        self.run(1)
+
+    def step_staged(self):
+        """the same step through the per-stage entry points (one host call per stage)"""
         c = self.ctx
         # what MovingObstacle*.get() would return for every agent: (x, y, v, yaw, a, steer)
         self.obs6[:, 0:2] = self.state[:, 0:2]
@@ -71,9 +100,8 @@ class IntersectionBatch:
         self.obs6[:, 4] = self.applied[:, 1]
         self.obs6[:, 5] = self.applied[:, 0]
         c.interaction(self.ip, self.state, self.path, self.path_cs, self.path_off, self.path_len,
-                      self.prev_cut if self.steps_done else None, self.obs6, self.obs_off, self.obs_cnt, self.obs_skip,
+                      self.inter['cut_len'], self.obs6, self.obs_off, self.obs_cnt, self.obs_skip,
                       self.traj_idx, out=self.inter)
-        self.prev_cut.copy_(self.inter['cut_len'])
         # the previous solution (zeros where the last solve failed or on the first step) is the warm start
         c.prepare(self.state, self.sol['u'], self.path, self.path_off, self.inter['cut_len'], self.dl, self.target_ind, out=self.pre)
         c.qp_solve(self.state, self.pre['xref'], self.pre['xbar'], self.pre['reaches_end'], self.sol['u'], out=self.sol)
@@ -83,8 +111,9 @@ class IntersectionBatch:
     def snapshot(self):
         """host copies of the per-agent state (synchronises)"""
         self.ctx.synchronize()
-        keys = ('state', 'applied', 'traj_idx', 'target_ind', 'prev_cut')
+        keys = ('state', 'applied', 'traj_idx', 'target_ind')
         out = {k: getattr(self, k).cpu().numpy().copy() for k in keys}
+        out['prev_cut'] = self.inter['cut_len'].cpu().numpy().copy()
         out.update({k: v.cpu().numpy().copy() for k, v in self.sol.items()})
         out.update({k: v.cpu().numpy().copy() for k, v in self.inter.items()})
         out.update({k: v.cpu().numpy().copy() for k, v in self.pre.items()})

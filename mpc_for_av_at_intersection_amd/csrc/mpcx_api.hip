@@ -41,12 +41,18 @@ mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
         c->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     c->pred_cap = 0;
+    c->loop_exec = nullptr;
+    c->prof_qp = false;
+    memset(c->loop_key, 0, sizeof c->loop_key);
     c->err[0] = 0;
     return c;
 }
 
 void mpcx_destroy(mpcx_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->loop_exec) { (void)hipStreamSynchronize(ctx->stream); (void)hipGraphExecDestroy(ctx->loop_exec); }
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     delete ctx;
@@ -61,6 +67,30 @@ int32_t mpcx_set_mpc_params(mpcx_ctx *ctx, const mpcx_mpc_params *p) {
         return mpcx_fail(ctx, MPCX_E_INVALID, "dt, L, tol must be positive and max_iter >= 1");
     ctx->mpc = *p;
     ctx->have_mpc = true;
+    return MPCX_OK;
+}
+
+int32_t mpcx_profile_qp(mpcx_ctx *ctx, int32_t enable) {
+    if (!ctx) return MPCX_E_INVALID;
+    ctx->prof_qp = enable != 0;
+    return MPCX_OK;
+}
+
+int32_t mpcx_profile_qp_read(mpcx_ctx *ctx, double *total_ms, int32_t *launches) {
+    if (!ctx || !total_ms || !launches) return MPCX_E_INVALID;
+    double sum = 0.0;
+    const size_t n = ctx->prof_ev.size() / 2;
+    for (size_t i = 0; i < n; i++) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ctx->prof_ev[2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) != hipSuccess)
+            return mpcx_fail(ctx, MPCX_E_LAUNCH, "profile_qp_read: event %zu could not be read", i);
+        sum += ms;
+    }
+    ctx->prof_free.insert(ctx->prof_free.end(), ctx->prof_ev.begin(), ctx->prof_ev.end());
+    ctx->prof_ev.clear();
+    *total_ms = sum;
+    *launches = (int32_t)n;
     return MPCX_OK;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mpcx.h"
+#include <vector>
 
 struct mpcx_ctx {
     int device;
@@ -13,11 +14,18 @@ struct mpcx_ctx {
     int n_cu;            // compute units of the device
     double *pred;        // scratch: predicted obstacle disc centres [NOBS][steps][2 discs][2]
     size_t pred_cap;     // capacity of pred in doubles
+    hipGraphExec_t loop_exec;   // cached one-step graph of mpcx_closed_loop_run (nullptr = none)
+    unsigned char loop_key[640]; // descriptor + parameters the cached graph was captured for
+    bool prof_qp;               // bracket qp_kernel launches with events (mpcx_profile_qp)
+    std::vector<hipEvent_t> prof_ev;   // start/stop pairs recorded so far
+    std::vector<hipEvent_t> prof_free; // recycled events
     char err[256];
 };
 
 int32_t mpcx_fail(mpcx_ctx *ctx, int32_t code, const char *fmt, ...);
 int32_t mpcx_check_launch(mpcx_ctx *ctx, const char *what);
+int32_t mpcx_ensure_pred(mpcx_ctx *ctx, size_t need_doubles);   // prediction scratch (mpcx_interaction.hip)
+int32_t mpcx_ensure_ticket(mpcx_ctx *ctx);                      // work-queue word (mpcx_qp.hip)
 
 namespace mpcx {
 

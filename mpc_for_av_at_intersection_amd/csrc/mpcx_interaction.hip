@@ -403,7 +403,6 @@ __global__ __launch_bounds__(64) void moving_collision_kernel(MovArgs a) {
 
 }  // namespace mpcx
 
-static int32_t ensure_pred(mpcx_ctx *ctx, size_t need);
 
 extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip, int32_t P,
                                           const double *state, const double *path_xyyaw, const double *path_cs,
@@ -419,7 +418,7 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
     if (ip->pred_steps < 1 || ip->pred_steps > MPCX_PRED_STEPS_MAX || ip->frame_window < 0 || !(ip->dt > 0) || !(ip->L > 0))
         return mpcx_fail(ctx, MPCX_E_INVALID, "interaction_batch: pred_steps outside 1..%d or bad dt/L/frame_window", MPCX_PRED_STEPS_MAX);
     if (P == 0) return MPCX_OK;
-    { int32_t rc = ensure_pred(ctx, (size_t)(n_obs_pool > 0 ? n_obs_pool : 1) * ip->pred_steps * 4); if (rc != MPCX_OK) return rc; }
+    { int32_t rc = mpcx_ensure_pred(ctx, (size_t)(n_obs_pool > 0 ? n_obs_pool : 1) * ip->pred_steps * 4); if (rc != MPCX_OK) return rc; }
     if (n_obs_pool > 0) {
         mpcx::PredArgs pa{*ip, n_obs_pool, obs6, ctx->pred};
         hipLaunchKernelGGL(mpcx::predict_kernel, dim3((n_obs_pool + 255) / 256), dim3(256), 0, ctx->stream, pa);
@@ -430,7 +429,7 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
     return mpcx_check_launch(ctx, "interaction kernels");
 }
 
-static int32_t ensure_pred(mpcx_ctx *ctx, size_t need) {
+int32_t mpcx_ensure_pred(mpcx_ctx *ctx, size_t need) {
     if (need <= ctx->pred_cap) return MPCX_OK;
     if (ctx->pred) (void)hipFree(ctx->pred);
     ctx->pred = nullptr; ctx->pred_cap = 0;
@@ -456,7 +455,7 @@ extern "C" int32_t mpcx_moving_collision_batch(mpcx_ctx *ctx, const mpcx_interac
         return mpcx_fail(ctx, MPCX_E_INVALID, "moving_collision_batch: pred_steps outside 1..%d or negative frame_window", MPCX_PRED_STEPS_MAX);
     if (P == 0) return MPCX_OK;
     const size_t nposes = (size_t)n_obs_pool * ip->pred_steps;
-    int32_t rc = ensure_pred(ctx, (nposes ? nposes : 1) * 4);
+    int32_t rc = mpcx_ensure_pred(ctx, (nposes ? nposes : 1) * 4);
     if (rc != MPCX_OK) return rc;
     if (nposes) {
         mpcx::PoseDiscArgs pd{*ip, (int)nposes, obs_xyyaw, obs_cs, ctx->pred};

@@ -1,0 +1,106 @@
+// mpcx_loop.hip -- the reference's scenario loop body (main/scenarios/mpc_intersection.py:95-159) for P agents as a
+// device-resident pipeline: n_steps x [pool pack -> predict -> conflict search + path cut -> reference window ->
+// rollout -> QP -> plant], enqueued back to back on the context's stream (optionally as a replayed hipGraph), no
+// host synchronisation or host arithmetic in between.  Every stage is the kernel behind the per-stage C entry
+// point, called with the very buffers the descriptor names, so a run is bit-identical to driving the stages one
+// by one from the host.
+#include "mpcx_common.h"
+#include <cstring>
+
+namespace mpcx {
+
+struct PackArgs {
+    int P;
+    const double *state, *applied;
+    double *obs6;
+};
+
+// MovingObstacle*.get() of the reference (mpc_intersection.py:119-122): (x, y, v, yaw, a, steer)
+__global__ __launch_bounds__(256) void pack_pool_kernel(PackArgs a) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.P) return;
+    double *o = a.obs6 + 6 * (size_t)q;
+    const double *s = a.state + 4 * (size_t)q;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
+    o[4] = a.applied[2 * q + 1];
+    o[5] = a.applied[2 * q];
+}
+
+}  // namespace mpcx
+
+static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *c) {
+    const int P = c->P;
+    mpcx::PackArgs pa{P, c->state, c->applied, c->obs6};
+    hipLaunchKernelGGL(mpcx::pack_pool_kernel, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, pa);
+    int32_t rc = mpcx_interaction_batch(ctx, ip, P, c->state, c->path_xyyaw, c->path_cs, c->path_off, c->path_len,
+                                        c->cut_len /* previous step's cut; read before it is rewritten */, P, c->obs6,
+                                        c->obs_off, c->obs_cnt, c->obs_skip, c->traj_idx, c->hit_idx, c->hit_xy, c->cut_len);
+    if (rc != MPCX_OK) return rc;
+    rc = mpcx_mpc_prepare_batch(ctx, P, c->state, c->u_sol, c->path_xyyaw, c->path_v, c->path_off, c->cut_len, c->dl,
+                                c->target_ind, c->xref, c->reaches_end, c->xbar);
+    if (rc != MPCX_OK) return rc;
+    rc = mpcx_qp_solve_batch(ctx, P, c->state, c->xref, c->xbar, c->reaches_end, c->u_sol, c->x_sol, c->u_sol,
+                             c->status, c->iters, c->kkt);
+    if (rc != MPCX_OK) return rc;
+    return mpcx_plant_step_batch(ctx, P, c->state, c->u_sol, c->status, c->applied);
+}
+
+extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *c,
+                                        int32_t n_steps, int32_t use_graph) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");
+    if (!ip || !c || n_steps < 0 || c->P < 0) return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: null descriptor or negative count");
+    if (n_steps == 0 || c->P == 0) return MPCX_OK;
+    if (!c->state || !c->applied || !c->obs6 || !c->path_xyyaw || !c->path_cs || !c->path_off || !c->path_len ||
+        !c->obs_off || !c->obs_cnt || !c->traj_idx || !c->target_ind || !c->hit_idx || !c->cut_len || !c->hit_xy ||
+        !c->xref || !c->xbar || !c->reaches_end || !c->x_sol || !c->u_sol || !c->status || !c->iters || !c->kkt || !(c->dl > 0))
+        return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: null buffer in the descriptor or dl <= 0");
+    if (ip->pred_steps < 1 || ip->pred_steps > MPCX_PRED_STEPS_MAX)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: pred_steps outside 1..%d", MPCX_PRED_STEPS_MAX);
+    // everything that allocates happens before the first launch (and outside any capture)
+    int32_t rc = mpcx_ensure_pred(ctx, (size_t)c->P * ip->pred_steps * 4);
+    if (rc != MPCX_OK) return rc;
+    rc = mpcx_ensure_ticket(ctx);
+    if (rc != MPCX_OK) return rc;
+
+    if (!use_graph) {
+        for (int s = 0; s < n_steps; s++) {
+            rc = enqueue_step(ctx, ip, c);
+            if (rc != MPCX_OK) return rc;
+        }
+        return MPCX_OK;
+    }
+
+    if (!ctx->stream) return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: graph replay needs a non-default stream");
+    unsigned char key[sizeof ctx->loop_key];
+    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + sizeof(void *) <= sizeof key,
+                  "loop_key too small");
+    memset(key, 0, sizeof key);
+    size_t o = 0;
+    memcpy(key + o, c, sizeof *c); o += sizeof *c;
+    memcpy(key + o, ip, sizeof *ip); o += sizeof *ip;
+    memcpy(key + o, &ctx->mpc, sizeof ctx->mpc); o += sizeof ctx->mpc;
+    memcpy(key + o, &ctx->pred, sizeof ctx->pred);
+    if (!ctx->loop_exec || memcmp(key, ctx->loop_key, sizeof key) != 0) {
+        if (ctx->loop_exec) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipGraphExecDestroy(ctx->loop_exec);
+            ctx->loop_exec = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+            return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipStreamBeginCapture failed");
+        rc = enqueue_step(ctx, ip, c);
+        hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        if (rc != MPCX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || !graph) return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: stream capture failed: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&ctx->loop_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { ctx->loop_exec = nullptr; return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        memcpy(ctx->loop_key, key, sizeof key);
+    }
+    for (int s = 0; s < n_steps; s++)
+        if (hipGraphLaunch(ctx->loop_exec, ctx->stream) != hipSuccess)
+            return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipGraphLaunch failed");
+    return MPCX_OK;
+}

@@ -611,6 +611,12 @@ static void launch_qp(const QpArgs &a, hipStream_t st, int grid) {
 
 }  // namespace mpcx
 
+int32_t mpcx_ensure_ticket(mpcx_ctx *ctx) {
+    if (!ctx->ticket && hipMalloc((void **)&ctx->ticket, sizeof(int32_t)) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "cannot allocate the work-queue word");
+    return MPCX_OK;
+}
+
 extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x0, const double *xref,
                                        const double *xbar, const uint8_t *reaches_end, const double *u_warm,
                                        double *x_out, double *u_out, int32_t *status, int32_t *iters, double *kkt) {
@@ -620,17 +626,29 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     if (B < 0 || !x0 || !xref || !xbar || !reaches_end || !x_out || !u_out || !status || !iters || !kkt)
         return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: null pointer or negative batch");
     if (B == 0) return MPCX_OK;
-    if (!ctx->ticket && hipMalloc((void **)&ctx->ticket, sizeof(int32_t)) != hipSuccess)
-        return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: cannot allocate the work-queue word");
+    { int32_t rc = mpcx_ensure_ticket(ctx); if (rc != MPCX_OK) return rc; }
     if (hipMemsetAsync(ctx->ticket, 0, sizeof(int32_t), ctx->stream) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipMemsetAsync failed");
     // persistent wavefronts: one per SIMD slot the kernel can occupy (1 wave/SIMD, 4 SIMDs/CU), never more than B
     const int grid = B < ctx->n_cu * 4 ? B : ctx->n_cu * 4;
     mpcx::QpArgs a{ctx->mpc, B, ctx->ticket, u_warm != nullptr, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (ctx->prof_qp && (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone)) {
+        for (hipEvent_t *e : {&e0, &e1}) {
+            if (!ctx->prof_free.empty()) { *e = ctx->prof_free.back(); ctx->prof_free.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipEventCreate failed");
+        }
+        (void)hipEventRecord(e0, ctx->stream);
+    }
     const int T = ctx->mpc.T;
     if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream, grid);
     else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream, grid);
     else if (T <= 20) mpcx::launch_qp<20>(a, ctx->stream, grid);
     else mpcx::launch_qp<32>(a, ctx->stream, grid);
+    if (e0) {
+        (void)hipEventRecord(e1, ctx->stream);
+        ctx->prof_ev.push_back(e0); ctx->prof_ev.push_back(e1);
+    }
     return mpcx_check_launch(ctx, "qp_kernel");
 }

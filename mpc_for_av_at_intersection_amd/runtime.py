@@ -248,6 +248,21 @@ class Context:
         self._chk(self.lib.mpcx_predict_obstacles_batch(self._ctx, n, int(steps), C.c_double(dt), C.c_double(L), _ptr(obs6), _ptr(out)))
         return out
 
+    def closed_loop_run(self, ip: InteractionParams, desc: '_lib.ClosedLoopC', n_steps: int, graph: bool = False):
+        """mpcx_closed_loop_run: n_steps of the scenario loop body on the buffers `desc` names, no host work between."""
+        cip = ip.to_c()
+        self._chk(self.lib.mpcx_closed_loop_run(self._ctx, C.byref(cip), C.byref(desc), int(n_steps), 1 if graph else 0))
+
+    def profile_qp(self, enable: bool):
+        """bracket every qp_kernel launch with HIP events on the context's stream (mpcx_profile_qp)"""
+        self._chk(self.lib.mpcx_profile_qp(self._ctx, 1 if enable else 0))
+
+    def profile_qp_read(self):
+        """(summed milliseconds, launches) of the bracketed qp_kernel launches since the last read"""
+        ms, n = C.c_double(0.0), C.c_int32(0)
+        self._chk(self.lib.mpcx_profile_qp_read(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def synchronize(self):
         self.stream.synchronize()
 

@@ -13,9 +13,8 @@ for rep in range(3):
     sim.obs6[:, 0:2] = sim.state[:, 0:2]; sim.obs6[:, 2] = sim.state[:, 2]; sim.obs6[:, 3] = sim.state[:, 3]
     sim.obs6[:, 4] = sim.applied[:, 1]; sim.obs6[:, 5] = sim.applied[:, 0]
     t.append(time.perf_counter())
-    c.interaction(sim.ip, sim.state, sim.path, sim.path_cs, sim.path_off, sim.path_len, sim.prev_cut, sim.obs6, sim.obs_off, sim.obs_cnt, sim.obs_skip, sim.traj_idx, out=sim.inter)
+    c.interaction(sim.ip, sim.state, sim.path, sim.path_cs, sim.path_off, sim.path_len, sim.inter["cut_len"], sim.obs6, sim.obs_off, sim.obs_cnt, sim.obs_skip, sim.traj_idx, out=sim.inter)
     t.append(time.perf_counter())
-    sim.prev_cut.copy_(sim.inter['cut_len'])
     t.append(time.perf_counter())
     c.prepare(sim.state, sim.sol['u'], sim.path, sim.path_off, sim.inter['cut_len'], sim.dl, sim.target_ind, out=sim.pre)
     t.append(time.perf_counter())
