@@ -209,6 +209,22 @@ int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, c
 int32_t mpcx_profile_qp(mpcx_ctx *ctx, int32_t enable);
 int32_t mpcx_profile_qp_read(mpcx_ctx *ctx, double *total_ms, int32_t *launches);
 
+/* ---- per-instance tuning: the quantities main/lib/mpc_sensitivity.py:150-163 re-reads from
+ * config/mpc_config_sensitivity.json before every solve, as one row per problem, so that a whole sensitivity sweep
+ * (scenarios/mpc_sensitivity_analysis.py: one closed loop per parameter set) runs as ONE batch.  While rows are set,
+ * problem b of every mpcx_qp_solve_batch / mpcx_plant_step_batch / mpcx_closed_loop_run call takes these fields
+ * from rows[b] instead of the context-wide parameter set -- the batch size must equal n_rows; everything else (T, dt, L, speed and
+ * steering limits, R_end, tolerances) still comes from mpcx_set_mpc_params.  rows is a DEVICE pointer that must
+ * stay valid while set; (NULL, 0) clears. */
+typedef struct {
+    double w_perp, w_para;
+    double R[2], Rd[2], Q_v_yaw[2];
+    double Qf[4];        /* ALREADY multiplied by T */
+    double max_accel, max_decel, max_dsteer /* rad/s */;
+    double reserved;
+} mpcx_qp_tuning;        /* 16 doubles */
+int32_t mpcx_set_instance_tuning(mpcx_ctx *ctx, const mpcx_qp_tuning *rows, int32_t n_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,9 +20,12 @@ from .runtime import Context, InteractionParams, MpcParams
 
 class IntersectionBatch:
     def __init__(self, ctx: Context, params: MpcParams, ip: InteractionParams, routes: Sequence[np.ndarray], dl: float,
-                 route_of_agent: np.ndarray, start_index: np.ndarray, v0: Optional[np.ndarray] = None):
+                 route_of_agent: np.ndarray, start_index: np.ndarray, v0: Optional[np.ndarray] = None,
+                 tuning: Optional[np.ndarray] = None):
         """routes: list of (n_r, 3) paths whose yaw column is already unwrapped (MPC.__init__, mpc.py:257);
-        route_of_agent, start_index: integer arrays of shape (B, A)."""
+        route_of_agent, start_index: integer arrays of shape (B, A); tuning: optional (B, 16) or (B*A, 16) array of
+        MpcParams.tuning_row()s -- one cost/limit set per instance (or agent), the batched form of the reference's
+        sensitivity sweeps (scenarios/mpc_sensitivity_analysis.py)."""
         self.ctx, self.params, self.ip, self.dl = ctx, params, ip, float(dl)
         ctx.set_mpc_params(params)
         route_of_agent = np.asarray(route_of_agent, dtype=np.int64)
@@ -64,6 +67,14 @@ class IntersectionBatch:
                         kkt=torch.zeros((P, 4), dtype=f, device=dev))
         self.steps_done = 0
         self.path_v = None
+        self.tuning = None
+        if tuning is not None:
+            tuning = np.asarray(tuning, dtype=np.float64)
+            if tuning.shape == (self.B, 16):
+                tuning = np.repeat(tuning, self.A, axis=0)
+            if tuning.shape != (P, 16):
+                raise ValueError('tuning must have shape (B, 16) or (B*A, 16)')
+            self.tuning = ctx.f64(tuning)
         self._desc = None
 
     def _descriptor(self) -> '_lib.ClosedLoopC':
@@ -84,6 +95,7 @@ class IntersectionBatch:
         """n_steps of the closed loop with no host work in between (mpcx_closed_loop_run)."""
         if self._desc is None:
             self._desc = self._descriptor()
+        self.ctx.set_instance_tuning(self.tuning)
         self.ctx.closed_loop_run(self.ip, self._desc, n_steps, graph)
         self.steps_done += n_steps
 
@@ -93,6 +105,7 @@ class IntersectionBatch:
     def step_staged(self):
         """the same step through the per-stage entry points (one host call per stage)"""
         c = self.ctx
+        c.set_instance_tuning(self.tuning)
         # what MovingObstacle*.get() would return for every agent: (x, y, v, yaw, a, steer)
         self.obs6[:, 0:2] = self.state[:, 0:2]
         self.obs6[:, 2] = self.state[:, 2]

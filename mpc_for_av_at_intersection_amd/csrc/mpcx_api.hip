@@ -43,6 +43,8 @@ mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
     c->pred_cap = 0;
     c->loop_exec = nullptr;
     c->prof_qp = false;
+    c->tune = nullptr;
+    c->tune_rows = 0;
     memset(c->loop_key, 0, sizeof c->loop_key);
     c->err[0] = 0;
     return c;
@@ -67,6 +69,15 @@ int32_t mpcx_set_mpc_params(mpcx_ctx *ctx, const mpcx_mpc_params *p) {
         return mpcx_fail(ctx, MPCX_E_INVALID, "dt, L, tol must be positive and max_iter >= 1");
     ctx->mpc = *p;
     ctx->have_mpc = true;
+    return MPCX_OK;
+}
+
+int32_t mpcx_set_instance_tuning(mpcx_ctx *ctx, const mpcx_qp_tuning *rows, int32_t n_rows) {
+    if (!ctx) return MPCX_E_INVALID;
+    if ((rows == nullptr) != (n_rows == 0) || n_rows < 0)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "set_instance_tuning: rows and n_rows must both be given or both be empty");
+    ctx->tune = rows;
+    ctx->tune_rows = n_rows;
     return MPCX_OK;
 }
 

@@ -16,6 +16,8 @@ struct mpcx_ctx {
     size_t pred_cap;     // capacity of pred in doubles
     hipGraphExec_t loop_exec;   // cached one-step graph of mpcx_closed_loop_run (nullptr = none)
     unsigned char loop_key[640]; // descriptor + parameters the cached graph was captured for
+    const mpcx_qp_tuning *tune; // per-instance tuning rows (device) or nullptr
+    int32_t tune_rows;
     bool prof_qp;               // bracket qp_kernel launches with events (mpcx_profile_qp)
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs recorded so far
     std::vector<hipEvent_t> prof_free; // recycled events

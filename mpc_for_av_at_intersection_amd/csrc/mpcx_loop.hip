@@ -73,14 +73,15 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
 
     if (!ctx->stream) return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: graph replay needs a non-default stream");
     unsigned char key[sizeof ctx->loop_key];
-    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + sizeof(void *) <= sizeof key,
+    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 2 * sizeof(void *) <= sizeof key,
                   "loop_key too small");
     memset(key, 0, sizeof key);
     size_t o = 0;
     memcpy(key + o, c, sizeof *c); o += sizeof *c;
     memcpy(key + o, ip, sizeof *ip); o += sizeof *ip;
     memcpy(key + o, &ctx->mpc, sizeof ctx->mpc); o += sizeof ctx->mpc;
-    memcpy(key + o, &ctx->pred, sizeof ctx->pred);
+    memcpy(key + o, &ctx->pred, sizeof ctx->pred); o += sizeof ctx->pred;
+    memcpy(key + o, &ctx->tune, sizeof ctx->tune);
     if (!ctx->loop_exec || memcmp(key, ctx->loop_key, sizeof key) != 0) {
         if (ctx->loop_exec) {
             (void)hipStreamSynchronize(ctx->stream);

@@ -97,6 +97,7 @@ struct PlantArgs {
     double *u;
     const int32_t *status;
     double *applied;
+    const mpcx_qp_tuning *tune;   // per-instance MAX_DECEL or nullptr
 };
 
 // MPC.step's tail (mpc.py:294-297) + Simulation.step
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
     const bool ok = !a.status || a.status[b] == MPCX_QP_OPTIMAL;
     if (ok) { di = a.u[(size_t)b * 2 * T + T]; ai = a.u[(size_t)b * 2 * T]; }
     else {
-        ai = a.p.max_decel;
+        ai = a.tune ? a.tune[b].max_decel : a.p.max_decel;
         for (int t = 0; t < 2 * T; t++) a.u[(size_t)b * 2 * T + t] = 0.0;   // warm start reset, mpc.py:222-224
     }
     a.applied[2 * b] = di; a.applied[2 * b + 1] = ai;
@@ -142,7 +143,9 @@ extern "C" int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state
     if (B == 0) return MPCX_OK;       // empty batch: nothing to do (zero-size tensors have null data pointers)
     if (B < 0 || !state || !u || !applied) return mpcx_fail(ctx, MPCX_E_INVALID, "plant_step_batch: null pointer");
     if (B == 0) return MPCX_OK;
-    mpcx::PlantArgs pa{ctx->mpc, B, state, u, status, applied};
+    if (ctx->tune && ctx->tune_rows != B)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "plant_step_batch: %d tuning rows are set but the batch has %d agents", ctx->tune_rows, B);
+    mpcx::PlantArgs pa{ctx->mpc, B, state, u, status, applied, ctx->tune};
     hipLaunchKernelGGL(mpcx::plant_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, pa);
     return mpcx_check_launch(ctx, "plant_kernel");
 }

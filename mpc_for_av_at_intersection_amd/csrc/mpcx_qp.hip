@@ -52,6 +52,8 @@ struct QpArgs {
     const uint8_t *re;
     double *x_out, *u_out, *kkt;
     int32_t *status, *iters;
+    const mpcx_qp_tuning *tune;   // per-problem rows or nullptr
+    int has_tune;                 // tune != NULL, tested on the host like has_warm
 };
 
 template <int NT>
@@ -143,7 +145,15 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     b = __builtin_amdgcn_readfirstlane(b);
     if (b >= a.B) break;
     lds_sync();                       // the previous problem's LDS reads are done before this one overwrites the tables
-    const mpcx_mpc_params &P = a.p;
+    mpcx_mpc_params P = a.p;
+    if (a.has_tune) {                 // wave-uniform row (b comes from readfirstlane): scalar loads
+        const mpcx_qp_tuning &tu = a.tune[b];
+        P.w_perp = tu.w_perp; P.w_para = tu.w_para;
+        P.R[0] = tu.R[0]; P.R[1] = tu.R[1]; P.Rd[0] = tu.Rd[0]; P.Rd[1] = tu.Rd[1];
+        P.Q_v_yaw[0] = tu.Q_v_yaw[0]; P.Q_v_yaw[1] = tu.Q_v_yaw[1];
+        P.Qf[0] = tu.Qf[0]; P.Qf[1] = tu.Qf[1]; P.Qf[2] = tu.Qf[2]; P.Qf[3] = tu.Qf[3];
+        P.max_accel = tu.max_accel; P.max_decel = tu.max_decel; P.max_dsteer = tu.max_dsteer;
+    }
     const int T = P.T, W = T + 1;
     const double dt = P.dt;
 
@@ -631,7 +641,10 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipMemsetAsync failed");
     // persistent wavefronts: one per SIMD slot the kernel can occupy (1 wave/SIMD, 4 SIMDs/CU), never more than B
     const int grid = B < ctx->n_cu * 4 ? B : ctx->n_cu * 4;
-    mpcx::QpArgs a{ctx->mpc, B, ctx->ticket, u_warm != nullptr, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters};
+    if (ctx->tune && ctx->tune_rows != B)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: %d tuning rows are set but the batch has %d problems", ctx->tune_rows, B);
+    mpcx::QpArgs a{ctx->mpc, B, ctx->ticket, u_warm != nullptr, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters,
+                   ctx->tune, ctx->tune != nullptr};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (ctx->prof_qp && (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone)) {

@@ -127,10 +127,16 @@ class MPC:
                 and np.array_equal(self._host_path[:n, 0], self.cx) and np.array_equal(self._host_path[:n, 2], self.cyaw)):
             self._upload()
 
+    def _make_params(self) -> MpcParams:
+        return _params(self.car_dimensions, self.dt)
+
+    def _fail_decel(self, p: MpcParams) -> float:
+        return globals()['MAX_DECEL']           # module constant, read at call time (mpc.py:296)
+
     # ------------------------------------------------------------------ one control step (mpc.py:280-299)
     def step(self, state: State) -> Tuple[float, float]:
         ctx = self._ctx
-        p = _params(self.car_dimensions, self.dt)
+        p = self._make_params()
         if ctx.params != p:
             ctx.set_mpc_params(p)
         Tn = p.T
@@ -157,7 +163,7 @@ class MPC:
         else:
             print("Error: Cannot solve mpc...", file=sys.stderr)
             self.oa = self.odelta = self.ox = self.oy = self.oyaw = self.ov = None
-            self.ai = MAX_DECEL
+            self.ai = self._fail_decel(p)
         return self.di, self.ai
 
     def get_current_xref_deviation(self):

@@ -46,6 +46,11 @@ class MpcParams:
         p.max_steer, p.max_dsteer, p.tol = float(self.max_steer), float(self.max_dsteer), float(self.tol)
         return p
 
+    def tuning_row(self) -> np.ndarray:
+        """the 16 doubles of mpcx_qp_tuning (include/mpcx.h) for this parameter set"""
+        return np.array([self.w_perp, self.w_para, *self.R, *self.Rd, *self.Q_v_yaw, *[float(q) * self.T for q in self.Qf_base],
+                         self.max_accel, self.max_decel, self.max_dsteer, 0.0], dtype=np.float64)
+
 
 @dataclass
 class InteractionParams:
@@ -252,6 +257,16 @@ class Context:
         """mpcx_closed_loop_run: n_steps of the scenario loop body on the buffers `desc` names, no host work between."""
         cip = ip.to_c()
         self._chk(self.lib.mpcx_closed_loop_run(self._ctx, C.byref(cip), C.byref(desc), int(n_steps), 1 if graph else 0))
+
+    def set_instance_tuning(self, rows: Optional[torch.Tensor]):
+        """mpcx_set_instance_tuning: rows (B,16) float64 device tensor (MpcParams.tuning_row per problem) or None to clear.
+        The tensor is kept alive by the context while set."""
+        if rows is None:
+            self._chk(self.lib.mpcx_set_instance_tuning(self._ctx, None, 0))
+        else:
+            self._want(rows, torch.float64, (rows.shape[0], 16), 'tuning rows')
+            self._chk(self.lib.mpcx_set_instance_tuning(self._ctx, _ptr(rows), int(rows.shape[0])))
+        self._tuning = rows
 
     def profile_qp(self, enable: bool):
         """bracket every qp_kernel launch with HIP events on the context's stream (mpcx_profile_qp)"""

@@ -181,3 +181,64 @@ def test_closed_loop_run_equals_staged_path_and_graph_replay(ctx):
     ctx.profile_qp(False)
     assert n == 3 and ms > 0.0
     side.close()
+
+
+def test_sensitivity_sweep_as_one_batch(ctx):
+    """Per-instance tuning rows (mpcx_set_instance_tuning): 32 closed loops with 32 different weight / limit sets -- the
+    sweep of scenarios/mpc_sensitivity_analysis.py -- advanced together; every step of every instance replayed on the
+    oracle with that instance's parameters.  Rows equal to the global parameters must change nothing, bit for bit."""
+    from dataclasses import replace
+    from mpc_for_av_at_intersection_amd.batch import IntersectionBatch, stock_routes, synthetic_batch
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams, MpcxError
+    from oracle import oracle_py as orc
+    routes, dl, cd = stock_routes(ctx)
+    B, T = 32, 13
+    rng = np.random.default_rng(5)
+    base = MpcParams(T=T, L=cd.distance_back_to_front_wheel)
+    sets = []
+    for b in range(B):
+        sets.append(replace(base, w_perp=float(rng.choice([1.0, 5.0, 20.0, 60.0])), w_para=float(rng.choice([0.2, 1.0, 4.0])),
+                            R=(float(rng.choice([0.01, 0.1])), float(rng.choice([0.01, 0.5]))),
+                            Rd=(float(rng.choice([0.01, 0.3])), float(rng.choice([0.2, 1.0, 3.0]))),
+                            Q_v_yaw=(float(rng.choice([0.0, 1.0])), float(rng.choice([0.1, 0.5, 2.0]))),
+                            Qf_base=(1.0, float(rng.choice([1.0, 2.0])), 0.0, float(rng.choice([0.5, 1.0]))),
+                            max_accel=float(rng.choice([1.0, 2.0, 3.0])), max_decel=float(rng.choice([-10.0, -5.0])),
+                            max_dsteer=float(np.deg2rad(rng.choice([15.0, 30.0, 60.0])))))
+    rows = np.stack([s.tuning_row() for s in sets])
+    ref = synthetic_batch(ctx, B=B, A=1, T=T, seed=2, routes=routes, dl=dl, cd=cd)
+    sim = IntersectionBatch(ctx, base, ref.ip, routes, dl, np.zeros((B, 1), np.int64) + np.arange(B)[:, None] % len(routes),
+                            ref.traj_idx.cpu().numpy().reshape(B, 1), tuning=rows)
+    tab = sim.path.cpu().numpy(); off = sim.path_off.cpu().numpy(); ln = sim.path_len.cpu().numpy()
+    centers = np.asarray(sim.ip.circle_centers).reshape(2, 2)
+    worst = 0.0
+    before = sim.snapshot()
+    spread = []
+    for step in range(8):
+        sim.step()
+        after = sim.snapshot()
+        assert (after['status'] == 0).all()
+        for q in range(B):
+            po = orc.MpcParams(**{k: getattr(sets[q], k) for k in ('T', 'dt', 'L', 'w_perp', 'w_para', 'R', 'Rd', 'Q_v_yaw', 'Qf_base',
+                                                                    'max_accel', 'max_decel', 'max_dsteer')})
+            r = orc.agent_step(po, tab[off[q]:off[q] + ln[q]], sim.dl, before['state'][q], np.zeros((0, 6)), int(before['traj_idx'][q]),
+                               int(before['prev_cut'][q]), int(before['target_ind'][q]), before['u'][q] if step else None,
+                               centers, sim.ip.radius, sim.ip.cutoff_margin)
+            assert r['sol'].status == 0 and r['target_ind'] == after['target_ind'][q]
+            worst = max(worst, np.abs(r['sol'].u - after['u'][q]).max(), np.abs(r['sol'].x - after['x'][q]).max())
+        spread.append(after['u'][:, 0, 0].copy())
+        before = after
+    assert worst < 2e-7, worst
+    assert np.ptp(spread[0]) > 0.5                      # the parameter sets really act (different first accelerations)
+    # uniform rows == global parameters: bit-identical to running without rows
+    a = synthetic_batch(ctx, B=8, A=8, T=T, seed=4, routes=routes, dl=dl, cd=cd)
+    b = synthetic_batch(ctx, B=8, A=8, T=T, seed=4, routes=routes, dl=dl, cd=cd)
+    b.tuning = ctx.f64(np.tile(a.params.tuning_row(), (b.P, 1)))
+    a.run(5); b.run(5)
+    sa, sb = a.snapshot(), b.snapshot()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    # a row count that does not match the batch is an error, not a silent broadcast
+    b.tuning = ctx.f64(np.tile(a.params.tuning_row(), (3, 1)))
+    with pytest.raises(MpcxError):
+        b.run(1)
+    ctx.set_instance_tuning(None)

@@ -166,3 +166,24 @@ def test_sharding_world_size_2_gloo():
     assert res[0][1:3] == (0, 5) and res[1][1:3] == (5, 10)
     for r in res:
         assert r[3] == [float(i) for i in range(10)]
+
+
+def test_sensitivity_config_to_tuning_row(tmp_path, monkeypatch):
+    """lib/mpc_sensitivity.py: the JSON keys of config/mpc_config_sensitivity.json map onto MpcParams / one mpcx_qp_tuning row"""
+    import json
+    cfg = {"NX": 4, "NU": 2, "T": 13, "w_perp": 7.0, "w_para": 0.5, "R": [0.02, 0.03], "Rd": [0.04, 2.0], "Q_v_yaw": [0.1, 0.6],
+           "Qf": [1.0, 2.0, 0.0, 0.5], "GOAL_DIS": 1.5, "STOP_SPEED": 0.1389, "MAX_TIME": 13.0, "MAX_ITER": 1, "DU_TH": 0.1,
+           "MAX_DSTEER": 45.0, "MAX_ACCEL": 1.5, "MAX_DECEL": -6}
+    path = tmp_path / 'mpc_config_sensitivity.json'
+    path.write_text(json.dumps(cfg))
+    monkeypatch.setenv('MPCX_MPC_SENSITIVITY_CONFIG', str(path))
+    from mpc_for_av_at_intersection_amd.lib import mpc_sensitivity as ms
+    from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions
+    p = ms.params_from_config(ms._load(), BicycleModelDimensions(), 0.2, horizon=13)
+    row = p.tuning_row()
+    assert row.shape == (16,)
+    assert np.allclose(row, [7.0, 0.5, 0.02, 0.03, 0.04, 2.0, 0.1, 0.6, 13.0, 26.0, 0.0, 6.5, 1.5, -6.0, np.deg2rad(45.0), 0.0])
+    # live reload: editing the file changes the next parameter set
+    cfg['w_perp'] = 33.0
+    path.write_text(json.dumps(cfg))
+    assert ms.params_from_config(ms._load(), BicycleModelDimensions(), 0.2).w_perp == 33.0
