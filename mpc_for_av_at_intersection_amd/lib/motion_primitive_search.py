@@ -1,11 +1,13 @@
 """Motion-primitive hybrid-A* planner with GPU successor generation.
 
-Call surface of the reference's three search variants:
-  main/lib/motion_primitive_search.py            (heuristic: distance to the goal BOX + 2.7*excess heading error)
-  main/lib/motion_primitive_search_modified.py   (heuristic: distance to the goal POINT + 2.7*(|dtheta| - tol/2))
-  main/lib/motion_primitive_search_multi_lane.py (weighted heuristic / edge cost terms)
-selected by `variant`; the sibling modules `motion_primitive_search_modified` / `_multi_lane` export the same class
-under the reference's names.
+Call surface of the reference's five search variants:
+  main/lib/motion_primitive_search.py             (heuristic: distance to the goal BOX + 2.7*excess heading error)
+  main/lib/motion_primitive_search_modified.py    (heuristic: distance to the goal POINT + 2.7*(|dtheta| - tol/2))
+  main/lib/motion_primitive_search_multi_lane.py  (weighted heuristic / edge cost terms)
+  main/lib/motion_primitive_search_roundabout.py  (modified heuristic; edge = length + 0.1/obstacle distance + 5*|dtheta|)
+  main/lib/motion_primitive_search_single_lane.py (heuristic + 15*|dtheta to goal|; edge = length + 5*|dtheta| + 0.1/obstacle distance)
+selected by `variant`; the sibling modules `motion_primitive_search_modified` / `_multi_lane` / `_roundabout` /
+`_single_lane` export the same class under the reference's names.
 
 Successors, collision flags and edge costs come from mpcx_expand_batch (one launch expands the popped node together
 with the best open nodes and, in a second launch, all of their free children, so most pops hit the cache); the
@@ -33,7 +35,7 @@ class MotionPrimitiveSearch:
                  wc_center: float = 0.0, variant: str = None, ctx=None):
         if variant is not None:
             self.variant = variant
-        if self.variant not in ('base', 'modified', 'multi_lane'):
+        if self.variant not in ('base', 'modified', 'multi_lane', 'roundabout', 'single_lane'):
             raise ValueError('unknown search variant %r' % (self.variant,))
         self._mps = mps
         self._car_dimensions = car_dimensions
@@ -113,8 +115,10 @@ class MotionPrimitiveSearch:
         gx, gy, gth = self._goal_point
         d_xy = np.sqrt((x - gx) ** 2 + (y - gy) ** 2)
         d_th = min(abs(theta - gth), abs(theta - gth) - self._allowed_goal_theta_difference / 2)
-        if self.variant == 'modified':                 # _modified.py:80-89
+        if self.variant in ('modified', 'roundabout'):  # _modified.py:80-89, _roundabout.py:131-157
             return d_xy + 2.7 * d_th
+        if self.variant == 'single_lane':              # _single_lane.py:145-162
+            return d_xy + 2.7 * d_th + 15 * self.calculate_steering_change_cost(node, self._goal_point, steering_angle_weight=1.0)
         steer = self.calculate_steering_change_cost(node, self._goal_point, steering_angle_weight=1.0)   # _multi_lane.py:155-181
         obst = 0.0
         centre = 0.0
@@ -156,10 +160,18 @@ class MotionPrimitiveSearch:
             name = self._names[k]
             self._points_to_mp_names[node, nb] = name
             length = self._mps[name].total_length
-            if self.variant != 'multi_lane':
+            if self.variant in ('base', 'modified'):
                 yield length, nb
                 continue
             steer = self.calculate_steering_change_cost(node, nb, steering_angle_weight=1.0)     # _multi_lane.py:226-237
+            if self.variant in ('roundabout', 'single_lane'):
+                d = self.distance_to_nearest_obstacle(nb)
+                obst = 1 / d if d else float('inf')
+                if self.variant == 'roundabout':       # _roundabout.py:212 (term order matters for the rounding)
+                    yield length + 0.1 * obst + 5 * steer, nb
+                else:                                  # _single_lane.py:218
+                    yield length + 5 * steer + 0.1 * obst, nb
+                continue
             obst = 0.0
             centre = 0.0
             if self._wh_obstacle != 0.0:               # (sic) the reference gates the COST term on the heuristic weight

@@ -497,12 +497,169 @@ def stage_closedloop():
     _savez('closedloop.npz', **out)
 
 
+def stage_traffic():
+    """scripted actors of main/lib/moving_obstacles.py: get()/step() tapes for every class and branch"""
+    import contextlib
+    import io
+    import numpy as np
+    from lib.car_dimensions import BicycleModelDimensions
+    from lib.moving_obstacles import (MovingObstacleArterial, MovingObstacleRoundabout, MovingObstacleTIntersection,
+                                      calculate_steering_angle_for_radius)
+    bic = BicycleModelDimensions()
+    cases = {}
+    k = 0
+    for cls, name in ((MovingObstacleTIntersection, 'tint'), (MovingObstacleRoundabout, 'round')):
+        for direction in (1, -1):
+            for turning in (True, False):
+                for offset, speed, dt in ((None, 25 / 3.6, 0.2), (1., 25 / 3.6, 0.2), (4., 20 / 3.6, 0.2), (0.5, 30 / 3.6, 0.1)):
+                    cases['%s/%d' % (name, k)] = (cls, dict(direction=direction, turning=turning, offset=offset, speed=speed, dt=dt))
+                    k += 1
+    for x0, y0, offset, speed in ((3.0, -30.0, None, 10 / 3.6), (-2.5, -12.0, 2.0, 15 / 3.6)):
+        cases['art/%d' % k] = (MovingObstacleArterial, dict(x_init=x0, y_init=y0, offset=offset, speed=speed, dt=0.2))
+        k += 1
+    out = {}
+    meta = {}
+    for key, (cls, kw) in cases.items():
+        o = cls(bic, **kw)
+        tape = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for _ in range(150):
+                tape.append(list(map(float, o.get())))
+                o.step()
+        out[key] = np.array(tape)
+        meta[key] = dict(cls=cls.__name__, **{a: (None if v is None else (bool(v) if isinstance(v, bool) else float(v))) for a, v in kw.items()})
+    out['arc_angle'] = np.array([calculate_steering_angle_for_radius(r) for r in (4.0, 5.0, 7.5)])
+    _savez('traffic.npz', **out)
+    with open(os.path.join(HERE, 'traffic_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def _world_arrays(sc):
+    """Scenario -> plain arrays (obstacle classes are matched by name: some envs import them through another package path)"""
+    import numpy as np
+    ga = sc.goal_area
+    kinds, params = [], []
+    for o in sc.obstacles:
+        if type(o).__name__ == 'BoxObstacle':
+            kinds.append(0)
+            params.append([*o.xy1, *o.xy2, float(o.hidden)])
+        else:
+            kinds.append(1)
+            params.append([*o.xy_center, o.radius, 0.0, float(o.hidden)])
+    return dict(start=np.array(sc.start, dtype=np.float64), goal_point=np.array(sc.goal_point, dtype=np.float64),
+                goal_area=np.array([*ga.xy1, *ga.xy2], dtype=np.float64), allowed_dtheta=np.array(sc.allowed_goal_theta_difference),
+                obst_kind=np.array(kinds, dtype=np.int32), obst_param=np.array(params, dtype=np.float64).reshape(-1, 5))
+
+
+def stage_worlds():
+    """every world the reference's main/envs/*.py can build, as obstacle-parameter tables (product data:
+    mpc_for_av_at_intersection_amd/data/worlds.npz) + golden A* runs on the non-stock worlds / remaining search variants"""
+    import contextlib
+    import io
+    import numpy as np
+    from envs.intersection import intersection
+    from envs.intersection_multi_lanes import intersection as intersection_ml
+    from envs.roundabout import roundabout as roundabout_small
+    from envs.roundabout_big import roundabout as roundabout_big
+    from envs.t_intersection import t_intersection
+    from lib.car_dimensions import BicycleModelDimensions
+    from lib.motion_primitive import load_motion_primitives
+    import lib.motion_primitive_search as mps_base
+    import lib.motion_primitive_search_multi_lane as mps_ml
+    import lib.motion_primitive_search_roundabout as mps_round
+    import lib.motion_primitive_search_single_lane as mps_single
+    worlds = {}
+    made = {}
+
+    def add(key, fn, **kw):
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                sc = fn(**kw)
+        except Exception as e:
+            print('world', key, 'not buildable:', repr(e))
+            return
+        made[key] = sc
+        for k, v in _world_arrays(sc).items():
+            worlds['%s/%s' % (key, k)] = v
+
+    for sp in (1, 2, 3, 4):
+        for ti in (1, 2, 3, 4):
+            if ti <= 3:
+                add('intersection/%d_%d' % (sp, ti), intersection, start_pos=sp, turn_indicator=ti)
+            add('t_intersection/%d_%d' % (sp, ti), t_intersection, start_pos=sp, turn_indicator=ti)
+            add('roundabout/%d_%d' % (sp, ti), roundabout_small, start_pos=sp, turn_indicator=ti)
+            add('roundabout_big/%d_%d' % (sp, ti), roundabout_big, start_pos=sp, turn_indicator=ti)
+            if ti <= 3:
+                for nl in (1, 2, 3):
+                    for sl in range(1, nl + 1):
+                        for gl in range(1, nl + 1):
+                            add('intersection_multi_lanes/%d_%d_%d_%d_%d' % (sp, ti, sl, gl, nl), intersection_ml, start_pos=sp,
+                                turn_indicator=ti, start_lane=sl, goal_lane=gl, number_of_lanes=nl)
+    try:
+        from envs.arterial_multi_lanes import ArterialMultiLanes
+        for nl in (1, 2, 3, 4):
+            for gl in range(1, nl + 1):
+                add('arterial/%d_%d' % (nl, gl), lambda nl=nl, gl=gl: ArterialMultiLanes(num_lanes=nl, goal_lane=gl).create_scenario())
+    except Exception as e:
+        print('arterial not importable:', repr(e))
+    path = os.path.join(REPO, 'mpc_for_av_at_intersection_amd', 'data', 'worlds.npz')
+    np.savez_compressed(path, **worlds)
+    print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024), len(made), 'worlds')
+
+    bic = BicycleModelDimensions()
+    mps_b = load_motion_primitives('bicycle_model')
+
+    def run_case(mod, sc, **kw):
+        names = sorted(mps_b.keys())
+        s = mod.MotionPrimitiveSearch(sc, bic, mps_b, margin=bic.radius, **kw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cost, path, traj = s.run(debug=True)
+        seq = [names.index(s._points_to_mp_names[a, b]) for a, b in zip(path[:-1], path[1:])]
+        dbg = s.debug_data
+        return dict(cost=np.array(cost), path=np.array(path, dtype=np.float64), seq=np.array(seq, dtype=np.int32),
+                    traj=np.asarray(traj, dtype=np.float64), dbg_node=np.array([d.node for d in dbg], dtype=np.float64),
+                    dbg_g=np.array([d.g for d in dbg], dtype=np.float64), dbg_h=np.array([d.h for d in dbg], dtype=np.float64))
+
+    runs = {}
+    todo = [('round', mps_round, 'roundabout_big/1_1', {}), ('round', mps_round, 'roundabout_big/2_2', {}),
+            ('round', mps_round, 'roundabout/1_3', {}), ('single', mps_single, 'intersection/4_1', {}),
+            ('single', mps_single, 'intersection/2_3', {}), ('base', mps_base, 't_intersection/1_1', {}),
+            ('base', mps_base, 't_intersection/2_2', {}), ('ml', mps_ml, 'intersection_multi_lanes/1_1_2_1_2', {}),
+            ('ml', mps_ml, 'intersection_multi_lanes/3_2_1_2_3', dict(wh_obstacle=0.2, wc_center=0.02))]
+    import signal
+
+    def _too_long(signum, frame):
+        raise TimeoutError('search exceeded its time box')
+    signal.signal(signal.SIGALRM, _too_long)
+    for tag, mod, key, kw in todo:
+        if key not in made:
+            print('skip', key)
+            continue
+        try:
+            signal.alarm(240)
+            try:
+                out = run_case(mod, made[key], **kw)
+            finally:
+                signal.alarm(0)
+        except BaseException as e:
+            print('search', tag, key, 'raised', repr(e))
+            continue
+        print(tag, key, 'cost %.3f' % float(out['cost']), len(out['dbg_g']), 'expansions')
+        for k, v in out.items():
+            runs['%s|%s/%s' % (tag, key, k)] = v
+    _savez('astar_worlds.npz', **runs)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--stage', default='numpy', choices=['numpy', 'closedloop', 'all'])
+    ap.add_argument('--stage', default='numpy', choices=['numpy', 'closedloop', 'traffic', 'worlds', 'all'])
     a = ap.parse_args()
     _enter_reference()
     if a.stage in ('numpy', 'all'):
         stage_numpy()
     if a.stage in ('closedloop', 'all'):
         stage_closedloop()
+    if a.stage in ('traffic', 'all'):
+        stage_traffic()
+    if a.stage in ('worlds', 'all'):
+        stage_worlds()

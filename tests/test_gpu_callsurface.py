@@ -222,3 +222,37 @@ def test_speed_reference_variant():
     m.set_trajectory_fromarray(full[:200], cutoff_idx=20)
     m.step(State(x=full[5, 0], y=full[5, 1], yaw=full[5, 2], v=5.0))
     assert m.status == 0 and m.ai < 0 and m.xref[2].min() == 0.0                  # zero speed reference ahead: brake
+
+
+def _world_cases():
+    import os
+    path = os.path.join(H.GOLD, 'astar_worlds.npz')
+    if not os.path.exists(path):
+        return []
+    return sorted({k.rsplit('/', 1)[0] for k in np.load(path).files})
+
+
+@pytest.mark.parametrize('case', _world_cases())
+def test_search_on_other_worlds_and_remaining_variants(case):
+    """Golden runs of the reference on the non-stock worlds (roundabouts, T-intersection, multi-lane intersection) and with
+    the `_roundabout` / `_single_lane` search variants: cost, primitive ids and expansion ORDER exact.  The worlds come from
+    data/worlds.npz through lib/scenario.py."""
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive_search import MotionPrimitiveSearch
+    from mpc_for_av_at_intersection_amd.lib.scenario import world
+    tag, key = case.split('|')
+    variant = {'round': 'roundabout', 'single': 'single_lane', 'base': 'base', 'ml': 'multi_lane'}[tag]
+    kw = dict(wh_obstacle=0.2, wc_center=0.02) if (tag == 'ml' and key.endswith('3_2_1_2_3')) else {}
+    cd, mps = _setup()
+    s = MotionPrimitiveSearch(world(key), cd, mps, margin=cd.radius, variant=variant, **kw)
+    runs = H.gold('astar_worlds.npz')
+    pre = case + '/'
+    cost, path, traj = s.run(debug=True)
+    assert cost == float(runs[pre + 'cost'])
+    assert len(path) == len(runs[pre + 'path']) and np.abs(np.array(path) - runs[pre + 'path']).max() < COORD_TOL
+    names = sorted(mps)
+    assert [names.index(s._points_to_mp_names[a, b]) for a, b in zip(path[:-1], path[1:])] == runs[pre + 'seq'].tolist()
+    dbg = s.debug_data
+    assert len(dbg) == len(runs[pre + 'dbg_g'])
+    assert np.abs(np.array([d.node for d in dbg]) - runs[pre + 'dbg_node']).max() < COORD_TOL
+    assert np.array_equal(np.array([d.g for d in dbg]), runs[pre + 'dbg_g'])
+    assert np.abs(traj - runs[pre + 'traj']).max() < COORD_TOL

@@ -187,3 +187,74 @@ def test_sensitivity_config_to_tuning_row(tmp_path, monkeypatch):
     cfg['w_perp'] = 33.0
     path.write_text(json.dumps(cfg))
     assert ms.params_from_config(ms._load(), BicycleModelDimensions(), 0.2).w_perp == 33.0
+
+
+def test_scripted_traffic_matches_reference_tapes():
+    """lib/moving_obstacles.py against get()/step() tapes recorded from the reference's classes (tests/golden/traffic.npz,
+    34 configurations x 150 steps: both directions, turning or not, start delays, plant dt 0.1/0.2): bit-identical"""
+    import contextlib
+    import io
+    import json
+    import os
+    from mpc_for_av_at_intersection_amd.lib import moving_obstacles as mo
+    from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions
+    tapes = H.gold('traffic.npz')
+    meta = json.load(open(os.path.join(H.GOLD, 'traffic_meta.json')))
+    bic = BicycleModelDimensions()
+    assert len(meta) == 34
+    turned = 0
+    for key, kw in meta.items():
+        kw = dict(kw)
+        cls = getattr(mo, kw.pop('cls'))
+        with contextlib.redirect_stdout(io.StringIO()):
+            got = cls(bic, **kw).tape(150)
+        assert np.array_equal(got, tapes[key]), key
+        turned += int(np.ptp(got[:, 3]) > 1.0)
+    assert turned >= 8                                            # the turning branches really turn
+    assert np.array_equal(tapes['arc_angle'], [mo.calculate_steering_angle_for_radius(r) for r in (4.0, 5.0, 7.5)])
+    # the stock scenario's traffic (mpc_intersection.py:49-52) equals the tape the interaction tests replay
+    mov = H.gold('moving.npz')
+    obs = [mo.MovingObstacleTIntersection(bic, direction=1, offset=2., turning=False, speed=25 / 3.6, dt=0.2),
+           mo.MovingObstacleTIntersection(bic, direction=-1, offset=4., turning=True, speed=25 / 3.6, dt=0.2)]
+    tape = np.stack([o.tape(120) for o in obs], axis=1)
+    assert np.array_equal(tape, mov['traffic/tape'])
+
+
+def test_world_tables_reproduce_reference_half_planes():
+    """lib/scenario.py + data/worlds.npz: the stock intersection worlds rebuilt from the tables give the reference's
+    half-plane arrays bit for bit (tests/golden/scenarios.npz holds `to_convex` outputs of the reference's own objects);
+    every tabulated world builds; closed-form worlds equal their tabulated twins."""
+    from mpc_for_av_at_intersection_amd.lib import scenario as sc
+    from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions, PriusDimensions
+    gold = H.gold('scenarios.npz')
+    for cd, tag in ((BicycleModelDimensions(), 'bic'), (PriusDimensions(), 'pri')):
+        for sp in (1, 2, 3, 4):
+            for ti in (1, 2, 3):
+                w = sc.intersection(turn_indicator=ti, start_pos=sp)
+                hp = np.concatenate([o.to_convex(margin=cd.radius) for o in w.obstacles], axis=0)
+                assert np.array_equal(hp, gold['int_%d_%d/hp_%s' % (sp, ti, tag)])
+                assert np.array_equal(np.array(w.start), gold['int_%d_%d/start' % (sp, ti)])
+    names = sc.available_worlds()
+    assert len(names) >= 200
+    kinds = {n.split('/')[0] for n in names}
+    assert {'intersection', 't_intersection', 'roundabout', 'roundabout_big', 'intersection_multi_lanes', 'arterial'} <= kinds
+    n_rows = {}
+    for n in names:
+        w = sc.world(n)
+        rows = sum(len(o.to_convex(0.5)) for o in w.obstacles)
+        assert rows <= 512 and len(w.obstacles) <= 128          # device table limits of mpcx_search_model_create
+        n_rows.setdefault(n.split('/')[0], set()).add(rows)
+        assert len(w.start) == 3 and len(w.goal_point) == 3 and w.goal_area.distance_to_point(w.goal_point[:2]) == 0
+    assert 128 in n_rows['intersection'] and max(n_rows['roundabout_big']) >= 152 and min(n_rows['t_intersection']) >= 80   # SURVEY 8(f)-4
+    for nl in (1, 2, 3, 4):
+        for gl in range(1, nl + 1):
+            a = sc.ArterialMultiLanes(num_lanes=nl, goal_lane=gl).create_scenario()
+            b = sc.world('arterial/%d_%d' % (nl, gl))
+            assert a.start == b.start and a.goal_point == b.goal_point
+            assert [o.xy1 + o.xy2 for o in a.obstacles] == [o.xy1 + o.xy2 for o in b.obstacles]
+            assert a.goal_area.xy1 + a.goal_area.xy2 == b.goal_area.xy1 + b.goal_area.xy2
+    assert sc.ArterialMultiLanes(num_lanes=2, goal_lane=3).create_scenario() is None
+    f = sc.free_area(test_no=2, angle=0.3, start_pos=1.0, goal_distance=10)
+    assert f.obstacles == [] and f.goal_point[2] == 0 and abs(f.goal_point[0] - (1.0 + 10 * np.cos(0.3))) < 1e-15
+    with pytest.raises(KeyError):
+        sc.t_intersection(turn_indicator=4, start_pos=4)        # the reference raises KeyError for this combination too
