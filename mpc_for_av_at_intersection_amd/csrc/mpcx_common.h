@@ -33,6 +33,23 @@ namespace mpcx {
 
 constexpr int WAVE = 64;
 
+struct QpArgs {
+    mpcx_mpc_params p;
+    int B;
+    int32_t *ticket;      // work queue head (zeroed before the launch): wavefronts draw QP indices until B is exhausted
+    int has_warm;         // u_warm != NULL (tested on the host: a device-side null test of a kernel-argument pointer trips a
+                          // gfx950 instruction-selection bug in some register-allocation outcomes)
+    const double *x0, *xref, *xbar, *u_warm;
+    const uint8_t *re;
+    double *x_out, *u_out, *kkt;
+    int32_t *status, *iters;
+    const mpcx_qp_tuning *tune;   // per-problem rows or nullptr
+    int has_tune;                 // tune != NULL, tested on the host like has_warm
+};
+
+void launch_qp_stage(const QpArgs &a, hipStream_t st);   // mpcx_qp_quad.hip
+
+
 __device__ __forceinline__ double rdlane(double v, int l) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, l);

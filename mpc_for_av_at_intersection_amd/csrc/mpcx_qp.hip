@@ -16,6 +16,8 @@
 // lane j keeps its (unscaled) Schur row as the transposed factor row, so both triangular sweeps run from
 // registers) and two solves whose pivots travel by v_readlane.
 #include "mpcx_common.h"
+#include <cstdlib>
+#include <cstring>
 
 #ifndef MPCX_CHUNK
 #define MPCX_CHUNK 40
@@ -42,19 +44,6 @@ namespace mpcx {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-struct QpArgs {
-    mpcx_mpc_params p;
-    int B;
-    int32_t *ticket;      // work queue head (zeroed before the launch): wavefronts draw QP indices until B is exhausted
-    int has_warm;         // u_warm != NULL (tested on the host: a device-side null test of a kernel-argument pointer trips a
-                          // gfx950 instruction-selection bug in some register-allocation outcomes)
-    const double *x0, *xref, *xbar, *u_warm;
-    const uint8_t *re;
-    double *x_out, *u_out, *kkt;
-    int32_t *status, *iters;
-    const mpcx_qp_tuning *tune;   // per-problem rows or nullptr
-    int has_tune;                 // tune != NULL, tested on the host like has_warm
-};
 
 template <int NT>
 struct QpShared {
@@ -655,7 +644,11 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         (void)hipEventRecord(e0, ctx->stream);
     }
     const int T = ctx->mpc.T;
-    if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream, grid);
+    // T <= 20: stage-structured solver, four lanes per problem (mpcx_qp_quad.hip); longer horizons (and MPCX_QP_KERNEL=wave):
+    // the condensed solver of this file, one wavefront per problem
+    static const bool force_wave = [] { const char *e = getenv("MPCX_QP_KERNEL"); return e && !strcmp(e, "wave"); }();
+    if (T <= 20 && !force_wave) mpcx::launch_qp_stage(a, ctx->stream);
+    else if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream, grid);
     else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream, grid);
     else if (T <= 20) mpcx::launch_qp<20>(a, ctx->stream, grid);
     else mpcx::launch_qp<32>(a, ctx->stream, grid);

@@ -1,0 +1,107 @@
+// mpcx_qp_quad.hip -- device build of the stage-structured QP solver (mpcx_qp_stage.h): FOUR lanes per problem, 16
+// problems per wavefront.  Lane q of a quad owns stages q*SPL .. q*SPL+SPL-1; the Riccati / costate / rollout sweeps hand
+// their carry to the neighbour lane with quad_perm DPP moves (full rate, no LDS), quad-wide reductions are two DPP steps,
+// slacks / multipliers / reciprocal slacks live in LDS as [row][lane] (conflict-free), everything else in registers.
+#include "mpcx_common.h"
+#include "mpcx_qp_stage.h"
+
+namespace mpcx {
+
+typedef __attribute__((address_space(3))) double lds_double;
+
+// group geometry: LQ_ = 4 (quad_perm selectors) or 8 (row shifts + half-row mirror), both inside one DPP row of 16 lanes
+template <int LQ_, int SPL_>
+struct GroupCx {
+    static constexpr int LQ = LQ_, SPL = SPL_;
+    static_assert(LQ == 4 || LQ == 8, "groups of 4 or 8 lanes");
+    int q, lane;
+    lds_double *sh;                       // s [SPL*8][64], lam [SPL*8][64], gains [SPL*8][64]
+    // quad_perm [1,2,3,3] / [0,0,1,2] = value of lane q+1 / q-1; row_shl:1 / row_shr:1 do the same across a whole row.
+    // The value arriving at a group's edge lane comes from the neighbouring group and is never used.
+    __device__ __forceinline__ double nxt(double v) const { return LQ == 4 ? dpp_mov<0xF9>(v, v) : dpp_mov<0x101>(v, v); }
+    __device__ __forceinline__ double prv(double v) const { return LQ == 4 ? dpp_mov<0x90>(v, v) : dpp_mov<0x111>(v, v); }
+    // butterflies: quad_perm [1,0,3,2] (xor 1), [2,3,0,1] (xor 2), row_half_mirror (lane i <-> 7-i of each half row)
+    __device__ __forceinline__ double gsum(double v) const {
+        v += dpp_mov<0xB1>(v, v); v += dpp_mov<0x4E>(v, v);
+        if (LQ == 8) v += dpp_mov<0x141>(v, v);
+        return v;
+    }
+    __device__ __forceinline__ double gmax(double v) const {
+        v = fmax(v, dpp_mov<0xB1>(v, v)); v = fmax(v, dpp_mov<0x4E>(v, v));
+        if (LQ == 8) v = fmax(v, dpp_mov<0x141>(v, v));
+        return v;
+    }
+    __device__ __forceinline__ double gmin(double v) const {
+        v = fmin(v, dpp_mov<0xB1>(v, v)); v = fmin(v, dpp_mov<0x4E>(v, v));
+        if (LQ == 8) v = fmin(v, dpp_mov<0x141>(v, v));
+        return v;
+    }
+    __device__ __forceinline__ bool gany(bool b) const {
+        const unsigned long long m = __ballot(b);
+        return ((m >> (lane & ~(LQ - 1))) & ((1ull << LQ) - 1ull)) != 0ull;
+    }
+    __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
+    __device__ __forceinline__ double rcp(double v) const { return frcp(v); }
+    __device__ __forceinline__ double rcp_fast(double v) const { return frcp1(v); }     // seed + one Newton step
+    // ratio tests only: the hardware seed; the 0.995 step margin is four orders of magnitude wider than its error
+    __device__ __forceinline__ double rcp_seed(double v) const { return __builtin_amdgcn_rcp(v); }
+    // phase boundary: LDS values are re-read afterwards instead of being carried in registers across the phase
+    __device__ __forceinline__ void fence() const { asm volatile("" ::: "memory"); }
+    __device__ __forceinline__ double ld_s(int k) const { return sh[(0 * SPL * 8 + k) * 64 + lane]; }
+    __device__ __forceinline__ double ld_l(int k) const { return sh[(1 * SPL * 8 + k) * 64 + lane]; }
+    __device__ __forceinline__ double ld_k(int k) const { return sh[(2 * SPL * 8 + k) * 64 + lane]; }
+    __device__ __forceinline__ void st_s(int k, double v) { sh[(0 * SPL * 8 + k) * 64 + lane] = v; }
+    __device__ __forceinline__ void st_l(int k, double v) { sh[(1 * SPL * 8 + k) * 64 + lane] = v; }
+    __device__ __forceinline__ void st_k(int k, double v) { sh[(2 * SPL * 8 + k) * 64 + lane] = v; }
+};
+
+template <int LQ, int SPL, bool TUNED>
+__global__ __launch_bounds__(64, 1) void qp_quad_kernel(QpArgs a) {
+    constexpr int PER_WAVE = 64 / LQ;
+    __shared__ double sh[3 * SPL * 8 * 64];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x * PER_WAVE + lane / LQ;
+    const bool valid = b < a.B;
+    const int bc = valid ? b : 0;
+    mpcx_mpc_params P = a.p;
+    if (TUNED) {
+        const mpcx_qp_tuning &tu = a.tune[bc];
+        P.w_perp = tu.w_perp; P.w_para = tu.w_para;
+        P.R[0] = tu.R[0]; P.R[1] = tu.R[1]; P.Rd[0] = tu.Rd[0]; P.Rd[1] = tu.Rd[1];
+        P.Q_v_yaw[0] = tu.Q_v_yaw[0]; P.Q_v_yaw[1] = tu.Q_v_yaw[1];
+        P.Qf[0] = tu.Qf[0]; P.Qf[1] = tu.Qf[1]; P.Qf[2] = tu.Qf[2]; P.Qf[3] = tu.Qf[3];
+        P.max_accel = tu.max_accel; P.max_decel = tu.max_decel; P.max_dsteer = tu.max_dsteer;
+    }
+    const int T = a.p.T, W = T + 1;
+    mpcx_stage::Problem pb{a.x0 + (size_t)bc * 4, a.xref + (size_t)bc * 4 * W, a.xbar + (size_t)bc * 4 * W,
+                           a.has_warm ? a.u_warm + (size_t)bc * 2 * T : nullptr, a.re + (size_t)bc * W,
+                           a.x_out + (size_t)bc * 4 * W, a.u_out + (size_t)bc * 2 * T, a.kkt + (size_t)bc * 4,
+                           a.status + bc, a.iters + bc};
+    GroupCx<LQ, SPL> cx{lane & (LQ - 1), lane, (lds_double *)sh};
+    mpcx_stage::solve(cx, P, pb, valid);
+}
+
+template <int LQ, int SPL>
+void launch_qp_group(const QpArgs &a, hipStream_t st) {
+    const int per_wave = 64 / LQ;
+    const int grid = (a.B + per_wave - 1) / per_wave;
+    if (a.has_tune) hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, true>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, false>), dim3(grid), dim3(64), 0, st, a);
+}
+
+void launch_qp_stage(const QpArgs &a, hipStream_t st) {
+    const int T = a.p.T;
+#ifndef MPCX_LQ
+#define MPCX_LQ 8
+#endif
+#if MPCX_LQ == 4
+    if (T <= 12) launch_qp_group<4, 3>(a, st);
+    else if (T <= 16) launch_qp_group<4, 4>(a, st);
+    else launch_qp_group<4, 5>(a, st);
+#else
+    if (T <= 16) launch_qp_group<8, 2>(a, st);
+    else launch_qp_group<8, 3>(a, st);
+#endif
+}
+
+}  // namespace mpcx

@@ -1,0 +1,632 @@
+// mpcx_qp_stage.h -- stage-structured interior-point solver for the MPC QP of lib/mpc.py:138-208.
+//
+// Same Mehrotra predictor-corrector iteration as the condensed solver (same residuals, step rules, safeguards and
+// exit conditions), but the Newton system  (H + G'DG) du = -(rd + G'w)  is never formed: because every cost and
+// constraint of the problem is local to one stage (x_t, u_t, u_{t-1}), the step is the solution of a
+// time-varying LQ problem and comes out of one backward Riccati sweep (6-state: dx, dy, dv, dpsi and the previous
+// input pair, which carries the input-rate cost and the steering-rate constraint) plus one forward sweep;
+// the two right-hand sides of the predictor-corrector reuse the stored gains.  O(T) work per iteration instead of
+// O(T^3), and a working set small enough that FOUR LANES hold one problem: lane q of a group owns SPL consecutive
+// stages, sweeps run as LQ "turns" (lane q works while the others wait) with the 6x6 cost-to-go handed to the
+// neighbour lane by DPP, and everything that is local to a stage (slacks, multipliers, residuals, step lengths)
+// runs on all lanes at once.  A wavefront therefore carries 64/LQ problems.
+//
+// The code is written against a small policy class (group geometry, neighbour hand-off, group reductions, row
+// storage) so that the SAME source runs on the host with one "lane" per problem; tests/ compiles that build with
+// g++ to check the algebra against the dense CPU restatement and under the sanitizers.  It is not a product path.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include "mpcx.h"
+
+#if defined(__HIPCC__)
+#define MPCX_HD __host__ __device__ __forceinline__
+#else
+#define MPCX_HD inline
+#endif
+#define MPCX_UNROLL _Pragma("unroll")
+#define MPCX_NOUNROLL _Pragma("nounroll")
+
+namespace mpcx_stage {
+
+// slot t (0..T-1) owns: input u_t, dynamics x_t -> x_{t+1}, the state x_{t+1} with its tracking cost, and 8 rows:
+//   0: a_t <= amax   1: -a_t <= -amin   2: d_t <= smax   3: -d_t <= smax
+//   4: d_t - d_{t-1} <= rmax   5: -(d_t - d_{t-1}) <= rmax   (t >= 1)
+//   6: v_{t+1} <= vmax   7: -v_{t+1} <= -vmin
+enum { ROWS = 8 };
+
+struct Problem {            // one QP (pointers to that problem's rows of the batch arrays)
+    const double *x0, *xref, *xbar, *u_warm;   // u_warm may be null
+    const uint8_t *re;
+    double *x_out, *u_out, *kkt;
+    int32_t *status, *iters;
+};
+
+template <class Cx>
+MPCX_HD void solve(Cx &cx, const mpcx_mpc_params &P, const Problem &pb, bool valid) {
+    constexpr int LQ = Cx::LQ, SPL = Cx::SPL;
+    const int q = cx.q;
+    const int T = P.T, W = T + 1;
+    const double dt = P.dt;
+    const double minv = 1.0 / (double)(8 * T - 2);
+    const int NTURN = (T + SPL - 1) / SPL < LQ ? (T + SPL - 1) / SPL : LQ;   // lanes q >= NTURN own no stage of this horizon
+
+    // ------------------------------------------------------------------ per-slot constants and iterate
+    double A0[SPL], A1[SPL], A2[SPL], A3[SPL], B3[SPL];       // a02, a03, a12, a13, b3 of mpc.py:58-79 (delta_bar = 0)
+    double Wxx[SPL], Wxy[SPL], Wyy[SPL];                      // 2*W_{t+1} xy block (mpc.py:157-170)
+    bool ended[SPL], uend[SPL];                               // x_{t+1} / u_t fall on the clipped tail of the reference (Qf / R_end)
+    double U0[SPL], U1[SPL];                                  // a_t, delta_t
+    double X0[SPL] = {}, X1[SPL] = {}, X2[SPL] = {}, X3[SPL] = {};    // x_{t+1}
+    bool act[SPL], rate[SPL];
+    double PH[SPL];                                           // yaw of the linearisation point (for C_t)
+    const double x00 = valid ? pb.x0[0] : 0.0, x01 = valid ? pb.x0[1] : 0.0, x02 = valid ? pb.x0[2] : 0.0, x03 = valid ? pb.x0[3] : 0.0;
+
+    MPCX_UNROLL
+    for (int ls = 0; ls < SPL; ls++) {
+        const int t = q * SPL + ls;
+        act[ls] = valid && t < T;
+        rate[ls] = act[ls] && t >= 1;
+        const int tc = act[ls] ? t : 0;
+        const double vb = act[ls] ? pb.xbar[2 * W + tc] : 0.0, ph = act[ls] ? pb.xbar[3 * W + tc] : 0.0;
+        double sn, cs;
+        sincos(ph, &sn, &cs);
+        A0[ls] = dt * cs; A1[ls] = -dt * vb * sn; A2[ls] = dt * sn; A3[ls] = dt * vb * cs; B3[ls] = dt * vb / P.L;
+        ended[ls] = act[ls] ? (pb.re[tc + 1] != 0) : false;
+        const double yr = act[ls] ? pb.xref[3 * W + tc + 1] : 0.0;
+        sincos(yr, &sn, &cs);
+        // perpendicular projector [[s^2, -sc], [-sc, c^2]] * w_perp + parallel projector [[c^2, cs], [cs, s^2]] * w_para
+        Wxx[ls] = 2.0 * (ended[ls] ? P.Qf[0] : (sn * sn) * P.w_perp + (cs * cs) * P.w_para);
+        Wxy[ls] = 2.0 * (ended[ls] ? 0.0 : (-sn * cs) * P.w_perp + (cs * sn) * P.w_para);
+        Wyy[ls] = 2.0 * (ended[ls] ? P.Qf[1] : (cs * cs) * P.w_perp + (sn * sn) * P.w_para);
+        uend[ls] = act[ls] ? (pb.re[tc] != 0) : false;
+        U0[ls] = (act[ls] && pb.u_warm) ? pb.u_warm[tc] : 0.0;
+        U1[ls] = (act[ls] && pb.u_warm) ? pb.u_warm[T + tc] : 0.0;
+        // slots beyond the horizon (and groups beyond the batch) carry all-zero data: every sweep below passes through them
+        // unchanged (zero dynamics, zero weights, rows off), so the code needs no per-slot branches
+        if (!act[ls]) { A0[ls] = A1[ls] = A2[ls] = A3[ls] = B3[ls] = 0.0; Wxx[ls] = Wxy[ls] = Wyy[ls] = 0.0; }
+        PH[ls] = ph;
+    }
+    const double Rda = 2.0 * P.Rd[0], Rds = 2.0 * P.Rd[1];
+    const double wv_run = 2.0 * P.Q_v_yaw[0], wp_run = 2.0 * P.Q_v_yaw[1], wv_end = 2.0 * P.Qf[2], wp_end = 2.0 * P.Qf[3];
+    const double ra_run = 2.0 * P.R[0], rs_run = 2.0 * P.R[1], ra_end = 2.0 * P.R_end[0], rs_end = 2.0 * P.R_end[1];
+#define WV(ls) (act[ls] ? (ended[ls] ? wv_end : wv_run) : 0.0)
+#define WP(ls) (act[ls] ? (ended[ls] ? wp_end : wp_run) : 0.0)
+#define RA_(ls) (uend[ls] ? ra_end : ra_run)
+#define RS_(ls) (uend[ls] ? rs_end : rs_run)
+
+    // ---- serial sweeps are written as "turns": lane `turn` works on its slots, then hands its carry to the neighbour
+    // forward rollout of the linear model from (u0, u1): fills (X0..X3); `free` = true uses u = 0 (free response)
+    auto rollout = [&](bool free_resp, double (&Y0)[SPL], double (&Y1)[SPL], double (&Y2)[SPL], double (&Y3)[SPL]) {
+        double c0 = x00, c1 = x01, c2 = x02, c3 = x03;
+        for (int turn = 0; turn < NTURN; turn++) {
+            if (q == turn) {
+                MPCX_UNROLL
+                for (int ls = 0; ls < SPL; ls++) {
+                    {
+                        const double ph = PH[ls];
+                        const double ua = free_resp ? 0.0 : U0[ls], us = free_resp ? 0.0 : U1[ls];
+                        // C_t = (dt v sin(phi) phi, -dt v cos(phi) phi, 0, 0) = (-a03 phi, -a13 phi, 0, 0)
+                        const double n0 = c0 + A0[ls] * c2 + A1[ls] * c3 - A1[ls] * ph;
+                        const double n1 = c1 + A2[ls] * c2 + A3[ls] * c3 - A3[ls] * ph;
+                        const double n2 = c2 + dt * ua, n3 = c3 + B3[ls] * us;
+                        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+                    }
+                    Y0[ls] = c0; Y1[ls] = c1; Y2[ls] = c2; Y3[ls] = c3;
+                }
+            }
+            if (turn + 1 < NTURN) {
+                const double t0 = cx.prv(c0), t1 = cx.prv(c1), t2 = cx.prv(c2), t3 = cx.prv(c3);
+                if (q == turn + 1) { c0 = t0; c1 = t1; c2 = t2; c3 = t3; }
+            }
+        }
+    };
+    // backward costate sweep: p_t = qx_t + A_t' p_{t+1};  out[ls] = ru[ls] + B_t' p_{t+1} (condensed gradient entries)
+    auto costate = [&](const double (&Q0)[SPL], const double (&Q1)[SPL], const double (&Q2)[SPL], const double (&Q3)[SPL],
+                       const double (&G0)[SPL], const double (&G1)[SPL], double (&O0)[SPL], double (&O1)[SPL]) {
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        for (int turn = NTURN - 1; turn >= 0; turn--) {
+            if (q == turn) {
+                MPCX_UNROLL
+                for (int ls = SPL - 1; ls >= 0; ls--) {
+                    {
+                        p0 += Q0[ls]; p1 += Q1[ls]; p2 += Q2[ls]; p3 += Q3[ls];          // gradient of x_{t+1}
+                        O0[ls] = G0[ls] + dt * p2;
+                        O1[ls] = G1[ls] + B3[ls] * p3;
+                        const double n2 = A0[ls] * p0 + A2[ls] * p1 + p2, n3 = A1[ls] * p0 + A3[ls] * p1 + p3;
+                        p2 = n2; p3 = n3;
+                    }
+                }
+            }
+            if (turn > 0) {
+                const double t0 = cx.nxt(p0), t1 = cx.nxt(p1), t2 = cx.nxt(p2), t3 = cx.nxt(p3);
+                if (q == turn - 1) { p0 = t0; p1 = t1; p2 = t2; p3 = t3; }
+            }
+        }
+    };
+
+    // neighbours of a per-slot value: previous slot (t-1) / next slot (t+1), across lanes where needed
+    auto prev_of = [&](const double (&V)[SPL], double (&O)[SPL]) {
+        const double from = cx.prv(V[SPL - 1]);
+        O[0] = (q > 0) ? from : 0.0;
+        MPCX_UNROLL
+        for (int ls = 1; ls < SPL; ls++) O[ls] = V[ls - 1];
+    };
+    auto next_of = [&](const double (&V)[SPL], double (&O)[SPL]) {
+        const double from = cx.nxt(V[0]);
+        O[SPL - 1] = (q + 1 < LQ) ? from : 0.0;
+        MPCX_UNROLL
+        for (int ls = 0; ls + 1 < SPL; ls++) O[ls] = V[ls + 1];
+    };
+
+    // ------------------------------------------------------------------ scaling norms, initial point (same rules as the condensed solver)
+    int status = MPCX_QP_MAXITER, it = 0;
+    double res_d = 0.0, res_p = 0.0, mu = 0.0;
+    const bool feasible0 = !(x02 > P.max_speed + 1e-9 || x02 < P.min_speed - 1e-9);
+    double gnorm = 1.0;
+    {
+        double F0[SPL] = {}, F1[SPL] = {}, F2[SPL] = {}, F3[SPL] = {}, Q0[SPL], Q1[SPL], Q2[SPL], Q3[SPL], Z[SPL], O0[SPL] = {}, O1[SPL] = {};
+        rollout(true, F0, F1, F2, F3);
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++) {
+            const int t = q * SPL + ls;
+            const int tc = t + 1 <= T ? t + 1 : T;        // slots beyond the horizon read a valid column; their weights are zero
+            const double e0 = F0[ls] - pb.xref[0 * W + tc], e1 = F1[ls] - pb.xref[1 * W + tc];
+            const double e2 = F2[ls] - pb.xref[2 * W + tc], e3 = F3[ls] - pb.xref[3 * W + tc];
+            Q0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; Q1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; Q2[ls] = WV(ls) * e2; Q3[ls] = WP(ls) * e3;
+            Z[ls] = 0.0;
+        }
+        costate(Q0, Q1, Q2, Q3, Z, Z, O0, O1);
+        double gm = 0.0;
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++) gm = fmax(gm, fmax(fabs(O0[ls]), fabs(O1[ls])));
+        gnorm = fmax(1.0, cx.gmax(gm));
+    }
+    const double rmax = P.max_dsteer * dt;
+    const double hnorm = fmax(fmax(fmax(1.0, fabs(P.max_accel)), fmax(fabs(P.max_decel), fabs(P.max_steer))),
+                              fmax(fabs(rmax), fmax(fabs(P.max_speed - x02), fabs(x02 - P.min_speed))));
+    rollout(false, X0, X1, X2, X3);
+    // rows: residual of row r at the current iterate WITHOUT the slack: g_r(u, x) - h_r
+    double Dprev[SPL];
+    auto row_gap = [&](int ls, int r, double dprev) -> double {
+        switch (r) {
+            case 0: return U0[ls] - P.max_accel;
+            case 1: return -U0[ls] + P.max_decel;
+            case 2: return U1[ls] - P.max_steer;
+            case 3: return -U1[ls] - P.max_steer;
+            case 4: return (U1[ls] - dprev) - rmax;
+            case 5: return -(U1[ls] - dprev) - rmax;
+            case 6: return X2[ls] - P.max_speed;
+            default: return -X2[ls] + P.min_speed;
+        }
+    };
+    auto row_on = [&](int ls, int r) -> bool { return (r == 4 || r == 5) ? rate[ls] : act[ls]; };
+    prev_of(U1, Dprev);
+    MPCX_UNROLL
+    for (int ls = 0; ls < SPL; ls++)
+        MPCX_UNROLL
+        for (int r = 0; r < ROWS; r++) {
+            const double si = -row_gap(ls, r, Dprev[ls]);
+            cx.st_s(ls * ROWS + r, row_on(ls, r) ? (si > 0.5 ? si : 0.5) : 1.0);
+            cx.st_l(ls * ROWS + r, row_on(ls, r) ? 1.0 : 0.0);
+        }
+
+    // gradient of the cost (no multipliers) wrt x_{t+1} and u_t at the current iterate; recomputed where needed rather than
+    // kept across the Riccati sweep (30 doubles per lane that the sweep needs for the cost-to-go)
+    auto cost_grad = [&](double (&G0)[SPL], double (&G1)[SPL], double (&G2)[SPL], double (&G3)[SPL], double (&H0)[SPL], double (&H1)[SPL]) {
+        double Un0[SPL], Un1[SPL], Up0[SPL], Up1[SPL];
+        prev_of(U1, Up1); prev_of(U0, Up0); next_of(U0, Un0); next_of(U1, Un1);
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++) {
+            const int t = q * SPL + ls;
+            const int tc = t + 1 <= T ? t + 1 : T;        // slots beyond the horizon read a valid column; their weights are zero
+            const double e0 = X0[ls] - pb.xref[0 * W + tc], e1 = X1[ls] - pb.xref[1 * W + tc];
+            const double e2 = X2[ls] - pb.xref[2 * W + tc], e3 = X3[ls] - pb.xref[3 * W + tc];
+            G0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; G1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; G2[ls] = WV(ls) * e2; G3[ls] = WP(ls) * e3;
+            const bool has_next = act[ls] && (t + 1 < T);
+            double g0 = RA_(ls) * U0[ls], g1 = RS_(ls) * U1[ls];
+            if (rate[ls]) { g0 += Rda * (U0[ls] - Up0[ls]); g1 += Rds * (U1[ls] - Up1[ls]); }
+            if (has_next) { g0 -= Rda * (Un0[ls] - U0[ls]); g1 -= Rds * (Un1[ls] - U1[ls]); }
+            H0[ls] = g0; H1[ls] = g1;               // zero on slots beyond the horizon (u = 0 there, no rate terms)
+        }
+    };
+
+    const double tol_loose = P.tol > 1e-7 ? P.tol : 1e-7;
+    int loose_run = 0;
+    bool loose = false;
+    const int max_iter = (valid && feasible0) ? P.max_iter : -1;
+    if (!feasible0) status = MPCX_QP_INFEASIBLE;
+    bool running = valid && feasible0;      // uniform within a group; other groups of the wave may still be running
+
+    // ------------------------------------------------------------------ iterations
+    // `cx.any(running)` keeps every lane of the wavefront in the loop until all its groups are done (cross-lane
+    // operations need all lanes); a finished group keeps computing on frozen data and discards the results.
+    for (int guard = 0; guard <= P.max_iter + 1; guard++) {
+        if (!cx.any(running)) break;
+        // ---- local pass A: rows, complementarity, gradient pieces
+        prev_of(U1, Dprev);
+        double DSa[SPL], DSd[SPL], DSr[SPL], DSv[SPL];  // barrier weights d = lam/s summed over the row pairs
+        double PG0[SPL], PG1[SPL], PG2[SPL], PG3[SPL], PH0[SPL], PH1[SPL];     // predictor gradient wrt x_{t+1}, u_t
+        double L45[SPL], N45[SPL];                    // (lam4 - lam5), (nu4 - nu5) of the predictor
+        double QL2[SPL], QA2[SPL], RL0[SPL], RL1[SPL], RA0[SPL], RA1[SPL];
+        double mu_s = 0.0, rp_m = 0.0;
+        cost_grad(PG0, PG1, PG2, PG3, PH0, PH1);
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++) {
+            double lam[ROWS], nu[ROWS], dd[ROWS];
+            MPCX_UNROLL
+            for (int r = 0; r < ROWS; r++) {
+                const bool on = row_on(ls, r);
+                const double s = cx.ld_s(ls * ROWS + r), l = cx.ld_l(ls * ROWS + r);
+                const double is = cx.rcp(s);
+                const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
+                const double d = on ? l * is : 0.0;
+                dd[r] = d;
+                lam[r] = on ? l : 0.0; nu[r] = d * rp;
+                mu_s += on ? s * l : 0.0;
+                rp_m = fmax(rp_m, fabs(rp));
+            }
+            DSa[ls] = dd[0] + dd[1]; DSd[ls] = dd[2] + dd[3]; DSr[ls] = dd[4] + dd[5]; DSv[ls] = dd[6] + dd[7];
+            RL0[ls] = lam[0] - lam[1]; RL1[ls] = lam[2] - lam[3]; L45[ls] = lam[4] - lam[5]; QL2[ls] = lam[6] - lam[7];
+            RA0[ls] = nu[0] - nu[1]; RA1[ls] = nu[2] - nu[3]; N45[ls] = nu[4] - nu[5]; QA2[ls] = nu[6] - nu[7];
+        }
+        double L45n[SPL], N45n[SPL];
+        next_of(L45, L45n); next_of(N45, N45n);
+        // ---- dual residual: costate sweep with the multipliers
+        double O0[SPL] = {}, O1[SPL] = {};
+        {
+            double Q2t[SPL], R0t[SPL], R1t[SPL];
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) {
+                Q2t[ls] = PG2[ls] + QL2[ls];
+                R0t[ls] = PH0[ls] + RL0[ls];
+                R1t[ls] = PH1[ls] + RL1[ls] + L45[ls] - L45n[ls];
+            }
+            costate(PG0, PG1, Q2t, PG3, R0t, R1t, O0, O1);
+        }
+        // from here on PG / PH hold the predictor's linear terms (cost gradient + G' nu with nu = d * rp)
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++) {
+            PG2[ls] += QA2[ls];
+            PH0[ls] += RA0[ls];
+            PH1[ls] += RA1[ls] + N45[ls] - N45n[ls];
+        }
+        double rd_m = 0.0;
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++) rd_m = fmax(rd_m, fmax(fabs(O0[ls]), fabs(O1[ls])));
+        const double n_rd = cx.gmax(rd_m), n_rp = cx.gmax(rp_m), n_mu = cx.gsum(mu_s) * minv;
+        if (running) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
+        // ---- exit tests (uniform per group)
+        if (running) {
+            if (res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol) { status = MPCX_QP_OPTIMAL; running = false; }
+        }
+        if (running) {
+            loose = (res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose);
+            loose_run = loose ? loose_run + 1 : 0;
+            if (loose_run >= 4) { status = MPCX_QP_OPTIMAL; running = false; }
+            else if (it == max_iter) { if (loose) status = MPCX_QP_OPTIMAL; running = false; }
+        }
+
+        cx.fence();
+        // ---- backward sweep: Riccati factorisation + predictor gains.  Carry: cost-to-go Hessian Pm (6x6 symmetric, 21
+        // entries, row-major upper) and gradient pv (6) at z_{t+1} = (dx_{t+1}, du_t), EXCLUDING x_{t+1}'s own stage cost.
+        // gains: the 2x4 block of K that multiplies (dx, dy, dv, dpsi) lives in the policy's storage (cx.st_k / cx.ld_k, 8 per
+        // slot); the 2x2 block that multiplies the previous input pair is Huu^-1 diag(rho_a, rho_d) and is rebuilt from the
+        // pivots (I1, I2, LL) and the rate weights where it is used
+        double KA0[SPL] = {}, KA1[SPL] = {}, I1[SPL] = {}, I2[SPL] = {}, LL[SPL] = {}, RHd[SPL] = {};
+        bool RHon[SPL] = {};
+        auto prev_block = [&](int ls, double &ka4, double &ka5, double &kd4, double &kd5) {
+            const double ra = RHon[ls] ? Rda : 0.0, rd = RHd[ls];
+            kd4 = -LL[ls] * ra * I2[ls]; ka4 = ra * I1[ls] - LL[ls] * kd4;
+            kd5 = rd * I2[ls];           ka5 = -LL[ls] * kd5;
+        };
+        bool bad = false;
+        {
+            double Pm[21], pv[6];
+            MPCX_UNROLL
+            for (int i = 0; i < 21; i++) Pm[i] = 0.0;
+            MPCX_UNROLL
+            for (int i = 0; i < 6; i++) pv[i] = 0.0;
+            for (int turn = NTURN - 1; turn >= 0; turn--) {
+                if (q == turn) {
+                    MPCX_UNROLL
+                    for (int ls = SPL - 1; ls >= 0; ls--) {
+                        // index of (i,j), i<=j, in the packed upper triangle of a 6x6
+#define PX(i, j) ((i) * 6 - (i) * ((i) + 1) / 2 + (j))
+                        // 1. own state cost of x_{t+1} (+ speed barrier) and its gradient
+                        const double p00 = Pm[PX(0, 0)] + Wxx[ls], p01 = Pm[PX(0, 1)] + Wxy[ls], p11 = Pm[PX(1, 1)] + Wyy[ls];
+                        const double p02 = Pm[PX(0, 2)], p03 = Pm[PX(0, 3)], p04 = Pm[PX(0, 4)], p05 = Pm[PX(0, 5)];
+                        const double p12 = Pm[PX(1, 2)], p13 = Pm[PX(1, 3)], p14 = Pm[PX(1, 4)], p15 = Pm[PX(1, 5)];
+                        const double p22 = Pm[PX(2, 2)] + WV(ls) + DSv[ls];
+                        const double p23 = Pm[PX(2, 3)], p24 = Pm[PX(2, 4)], p25 = Pm[PX(2, 5)];
+                        const double p33 = Pm[PX(3, 3)] + WP(ls), p34 = Pm[PX(3, 4)], p35 = Pm[PX(3, 5)];
+                        const double p44 = Pm[PX(4, 4)], p45 = Pm[PX(4, 5)], p55 = Pm[PX(5, 5)];
+                        const double g0 = pv[0] + PG0[ls], g1 = pv[1] + PG1[ls], g2 = pv[2] + PG2[ls], g3 = pv[3] + PG3[ls];
+                        const double g4 = pv[4], g5 = pv[5];
+                        const double a0 = A0[ls], a1 = A1[ls], a2 = A2[ls], a3 = A3[ls], b3 = B3[ls];
+                        // 2. G = P * F  (columns v, psi, a, delta of F = d z_{t+1} / d (x, y, v, psi, a, delta))
+                        const double Gv0 = a0 * p00 + a2 * p01 + p02, Gv1 = a0 * p01 + a2 * p11 + p12, Gv2 = a0 * p02 + a2 * p12 + p22;
+                        const double Gp0 = a1 * p00 + a3 * p01 + p03, Gp1 = a1 * p01 + a3 * p11 + p13, Gp2 = a1 * p02 + a3 * p12 + p23;
+                        const double Gp3 = a1 * p03 + a3 * p13 + p33;
+                        const double Ga0 = dt * p02 + p04, Ga1 = dt * p12 + p14, Ga2 = dt * p22 + p24, Ga3 = dt * p23 + p34, Ga4 = dt * p24 + p44;
+                        const double Gd0 = b3 * p03 + p05, Gd1 = b3 * p13 + p15, Gd2 = b3 * p23 + p25, Gd3 = b3 * p33 + p35;
+                        const double Gd4 = b3 * p34 + p45, Gd5 = b3 * p35 + p55;
+                        // 3. Phi = F' G
+                        const double Fvv = a0 * Gv0 + a2 * Gv1 + Gv2, Fvp = a0 * Gp0 + a2 * Gp1 + Gp2;
+                        const double Fva = a0 * Ga0 + a2 * Ga1 + Ga2, Fvd = a0 * Gd0 + a2 * Gd1 + Gd2;
+                        const double Fpp = a1 * Gp0 + a3 * Gp1 + Gp3, Fpa = a1 * Ga0 + a3 * Ga1 + Ga3, Fpd = a1 * Gd0 + a3 * Gd1 + Gd3;
+                        // 4. input, rate and barrier terms
+                        const double rho_a = rate[ls] ? Rda : 0.0;
+                        const double rho_d = rate[ls] ? Rds + DSr[ls] : 0.0;
+                        const double Faa = dt * Ga2 + Ga4 + RA_(ls) + DSa[ls] + rho_a;
+                        const double Fad = dt * Gd2 + Gd4;
+                        const double Fdd = b3 * Gd3 + Gd5 + RS_(ls) + DSd[ls] + rho_d;
+                        // 5. eliminate (a, delta): Huu = [[Faa, Fad], [Fad, Fdd]] = L D L'
+                        bad = bad || !(Faa > 0.0);
+                        const double i1 = cx.rcp(Faa > 0.0 ? Faa : 1.0);
+                        const double l = Fad * i1;
+                        const double s2 = Fdd - l * Fad;
+                        bad = bad || !(s2 > 0.0);
+                        const double i2 = cx.rcp(s2 > 0.0 ? s2 : 1.0);
+                        I1[ls] = i1; I2[ls] = i2; LL[ls] = l; RHd[ls] = rho_d; RHon[ls] = rate[ls];
+                        // Huz rows (columns x, y, v, psi, a-, d-)
+                        const double za[6] = {Ga0, Ga1, Fva, Fpa, -rho_a, 0.0};
+                        const double zd[6] = {Gd0, Gd1, Fvd, Fpd, 0.0, -rho_d};
+                        double ka[6], kd[6];
+                        MPCX_UNROLL
+                        for (int c = 0; c < 6; c++) {
+                            const double wd = zd[c] - l * za[c];
+                            kd[c] = -wd * i2;
+                            ka[c] = -za[c] * i1 - l * kd[c];
+                            if (c < 4) { cx.st_k(ls * 8 + c, ka[c]); cx.st_k(ls * 8 + 4 + c, kd[c]); }
+                        }
+                        // predictor gradient: hu = ru + B'p, hz = A'p
+                        const double hu0 = dt * g2 + g4 + PH0[ls];
+                        const double hu1 = b3 * g3 + g5 + PH1[ls];
+                        const double wd = hu1 - l * hu0;
+                        const double k1 = -wd * i2, k0 = -hu0 * i1 - l * k1;
+                        KA0[ls] = k0; KA1[ls] = k1;
+                        const double hz[6] = {g0, g1, a0 * g0 + a2 * g1 + g2, a1 * g0 + a3 * g1 + g3, 0.0, 0.0};
+                        // 6. new cost-to-go at z_t (without x_t's own cost): Hzz + Huz' K,  hz + K' hu
+                        const double zz[21] = {p00, p01, Gv0, Gp0, 0.0, 0.0,
+                                               p11, Gv1, Gp1, 0.0, 0.0,
+                                               Fvv, Fvp, 0.0, 0.0,
+                                               Fpp, 0.0, 0.0,
+                                               rho_a, 0.0,
+                                               rho_d};
+                        MPCX_UNROLL
+                        for (int i = 0; i < 6; i++)
+                            MPCX_UNROLL
+                            for (int j = i; j < 6; j++) Pm[PX(i, j)] = zz[PX(i, j)] + za[i] * ka[j] + zd[i] * kd[j];
+                        MPCX_UNROLL
+                        for (int i = 0; i < 6; i++) pv[i] = hz[i] + ka[i] * hu0 + kd[i] * hu1;
+                    }
+                }
+                if (turn > 0) {
+                    MPCX_UNROLL
+                    for (int i = 0; i < 21; i++) { const double tv = cx.nxt(Pm[i]); if (q == turn - 1) Pm[i] = tv; }
+                    MPCX_UNROLL
+                    for (int i = 0; i < 6; i++) { const double tv = cx.nxt(pv[i]); if (q == turn - 1) pv[i] = tv; }
+                }
+            }
+        }
+        const bool any_bad = cx.gany(bad);
+        if (running && any_bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; running = false; }
+
+        // forward sweep with gains (K, kk): fills the direction (du, dx_{t+1})
+        auto forward = [&](const double (&k0)[SPL], const double (&k1)[SPL], double (&D0)[SPL], double (&D1)[SPL],
+                           double (&E0)[SPL], double (&E1)[SPL], double (&E2)[SPL], double (&E3)[SPL]) {
+            double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int turn = 0; turn < NTURN; turn++) {
+                if (q == turn) {
+                    MPCX_UNROLL
+                    for (int ls = 0; ls < SPL; ls++) {
+                        {
+                            double da = k0[ls], dd = k1[ls];
+                            MPCX_UNROLL
+                            for (int c = 0; c < 4; c++) { da += cx.ld_k(ls * 8 + c) * z[c]; dd += cx.ld_k(ls * 8 + 4 + c) * z[c]; }
+                            {
+                                double ka4, ka5, kd4, kd5;
+                                prev_block(ls, ka4, ka5, kd4, kd5);
+                                da += ka4 * z[4] + ka5 * z[5]; dd += kd4 * z[4] + kd5 * z[5];
+                            }
+                            const double n0 = z[0] + A0[ls] * z[2] + A1[ls] * z[3], n1 = z[1] + A2[ls] * z[2] + A3[ls] * z[3];
+                            const double n2 = z[2] + dt * da, n3 = z[3] + B3[ls] * dd;
+                            z[0] = n0; z[1] = n1; z[2] = n2; z[3] = n3; z[4] = da; z[5] = dd;
+                            D0[ls] = da; D1[ls] = dd;
+                        }
+                        E0[ls] = z[0]; E1[ls] = z[1]; E2[ls] = z[2]; E3[ls] = z[3];
+                    }
+                }
+                if (turn + 1 < NTURN) {
+                    MPCX_UNROLL
+                    for (int i = 0; i < 6; i++) { const double tv = cx.prv(z[i]); if (q == turn + 1) z[i] = tv; }
+                }
+            }
+        };
+        // row direction g_r' (du, dx)
+        auto row_dir = [&](int r, double da, double dd, double ddprev, double dv) -> double {
+            switch (r) {
+                case 0: return da;
+                case 1: return -da;
+                case 2: return dd;
+                case 3: return -dd;
+                case 4: return dd - ddprev;
+                case 5: return -(dd - ddprev);
+                case 6: return dv;
+                default: return -dv;
+            }
+        };
+
+        cx.fence();
+        // ---- predictor direction, affine step length, centring parameter
+        double DA0[SPL] = {}, DA1[SPL] = {}, EA0[SPL] = {}, EA1[SPL] = {}, EA2[SPL] = {}, EA3[SPL] = {}, DAp[SPL];
+        forward(KA0, KA1, DA0, DA1, EA0, EA1, EA2, EA3);
+        prev_of(DA1, DAp);
+        double al = 1.0, c1 = 0.0, c2 = 0.0;
+        // per row, recomputed from (s, lam, u, x) wherever needed instead of being kept: rp = s + gap, d = lam / s
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++)
+            MPCX_UNROLL
+            for (int r = 0; r < ROWS; r++) {
+                const bool on = row_on(ls, r);
+                const double s = cx.ld_s(ls * ROWS + r), l = on ? cx.ld_l(ls * ROWS + r) : 0.0;
+                const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
+                const double d = l * cx.rcp(s);
+                const double dsa = on ? -rp - row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]) : 0.0;
+                const double dla = -l - d * dsa;
+                // ratio tests: any value <= the exact ratio is a valid step bound, the 0.995 margin absorbs the seed's error
+                al = fmin(al, (on && dsa < 0.0) ? -s * cx.rcp_fast(dsa) : 1.0);
+                al = fmin(al, (on && dla < 0.0) ? -l * cx.rcp_fast(dla) : 1.0);
+                c1 += on ? s * dla + l * dsa : 0.0;
+                c2 += dsa * dla;
+            }
+        const double alpha_aff = cx.gmin(al);
+        // mu_aff = sum (s + a dsa)(lam + a dla) / m = mu + a c1/m + a^2 c2/m
+        const double mu_aff = n_mu + alpha_aff * (cx.gsum(c1) * minv) + alpha_aff * alpha_aff * (cx.gsum(c2) * minv);
+        double sigma = mu_aff / (n_mu > 0.0 ? n_mu : 1.0);
+        sigma = sigma * sigma * sigma;
+        const double smu = sigma * n_mu;
+
+        cx.fence();
+        // ---- corrector: nu = (lam rp - alpha_aff dsa dla + sigma mu) / s ; backward vector sweep with the stored gains
+        double KC0[SPL] = {}, KC1[SPL] = {};
+        double RC[SPL][ROWS];           // rc / s of the corrector (kept in registers across the two corrector sweeps)
+        {
+            double C01[SPL], C23[SPL], C45[SPL], C67[SPL], C45n[SPL];
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) {
+                double nu[ROWS];
+                MPCX_UNROLL
+                for (int r = 0; r < ROWS; r++) {
+                    const bool on = row_on(ls, r);
+                    const double s = cx.ld_s(ls * ROWS + r), l = on ? cx.ld_l(ls * ROWS + r) : 0.0;
+                    const double is = cx.rcp(s);
+                    const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
+                    const double dsa = on ? -rp - row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]) : 0.0;
+                    const double dla = -l - (l * is) * dsa;
+                    const double rc = on ? s * l + alpha_aff * (dsa * dla) - smu : 0.0;
+                    RC[ls][r] = rc * is;                                         // rc / s
+                    nu[r] = on ? l + (l * rp) * is - rc * is : 0.0;
+                }
+                C01[ls] = nu[0] - nu[1]; C23[ls] = nu[2] - nu[3]; C45[ls] = nu[4] - nu[5]; C67[ls] = nu[6] - nu[7];
+            }
+            next_of(C45, C45n);
+            double CG0[SPL], CG1[SPL], CG2[SPL], CG3[SPL], CH0[SPL], CH1[SPL];
+            cost_grad(CG0, CG1, CG2, CG3, CH0, CH1);
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) { CG2[ls] += C67[ls]; CH0[ls] += C01[ls]; CH1[ls] += C23[ls] + C45[ls] - C45n[ls]; }
+            double pv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int turn = NTURN - 1; turn >= 0; turn--) {
+                if (q == turn) {
+                    MPCX_UNROLL
+                    for (int ls = SPL - 1; ls >= 0; ls--) {
+                        const double g0 = pv[0] + CG0[ls], g1 = pv[1] + CG1[ls], g2 = pv[2] + CG2[ls], g3 = pv[3] + CG3[ls];
+                        const double hu0 = dt * g2 + pv[4] + CH0[ls];
+                        const double hu1 = B3[ls] * g3 + pv[5] + CH1[ls];
+                        const double i1 = I1[ls], i2 = I2[ls], l = LL[ls];
+                        const double wd = hu1 - l * hu0;
+                        const double k1 = -wd * i2, k0 = -hu0 * i1 - l * k1;
+                        KC0[ls] = k0; KC1[ls] = k1;
+                        const double hz[6] = {g0, g1, A0[ls] * g0 + A2[ls] * g1 + g2, A1[ls] * g0 + A3[ls] * g1 + g3, 0.0, 0.0};
+                        MPCX_UNROLL
+                        for (int i = 0; i < 4; i++) pv[i] = hz[i] + cx.ld_k(ls * 8 + i) * hu0 + cx.ld_k(ls * 8 + 4 + i) * hu1;
+                        {
+                            double ka4, ka5, kd4, kd5;
+                            prev_block(ls, ka4, ka5, kd4, kd5);
+                            pv[4] = ka4 * hu0 + kd4 * hu1; pv[5] = ka5 * hu0 + kd5 * hu1;
+                        }
+                    }
+                }
+                if (turn > 0) {
+                    MPCX_UNROLL
+                    for (int i = 0; i < 6; i++) { const double tv = cx.nxt(pv[i]); if (q == turn - 1) pv[i] = tv; }
+                }
+            }
+        }
+        double D0[SPL] = {}, D1[SPL] = {}, E0[SPL] = {}, E1[SPL] = {}, E2[SPL] = {}, E3[SPL] = {}, Dp[SPL];
+        forward(KC0, KC1, D0, D1, E0, E1, E2, E3);
+        prev_of(D1, Dp);
+        // the gains are dead from here on: their storage takes the multiplier step dl (the slack step ds is recomputed)
+        cx.fence();
+        double am = 1e300;
+        auto slack_step = [&](int ls, int r, double s) -> double {
+            const bool on = row_on(ls, r);
+            const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
+            return on ? -rp - row_dir(r, D0[ls], D1[ls], Dp[ls], E2[ls]) : 0.0;
+        };
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++)
+            MPCX_UNROLL
+            for (int r = 0; r < ROWS; r++) {
+                const bool on = row_on(ls, r);
+                const double s = cx.ld_s(ls * ROWS + r), l = on ? cx.ld_l(ls * ROWS + r) : 0.0;
+                const double ds = slack_step(ls, r, s);
+                const double dl = on ? -RC[ls][r] - (l * cx.rcp(s)) * ds : 0.0;
+                cx.st_k(ls * ROWS + r, dl);
+                am = fmin(am, (on && ds < 0.0) ? -s * cx.rcp_fast(ds) : 1e300);
+                am = fmin(am, (on && dl < 0.0) ? -l * cx.rcp_fast(dl) : 1e300);
+            }
+        cx.fence();
+        double alpha = 0.995 * cx.gmin(am);
+        if (alpha > 1.0) alpha = 1.0;
+        // centrality safeguard: shorten until min s*lam >= 1e-3 * mean at the new point (at most 6 times)
+        for (int tr = 0; tr < 6; tr++) {
+            double pmin = 1e300, psum = 0.0;
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++)
+                MPCX_UNROLL
+                for (int r = 0; r < ROWS; r++) {
+                    const bool on = row_on(ls, r);
+                    const double s = cx.ld_s(ls * ROWS + r), l = cx.ld_l(ls * ROWS + r);
+                    const double pr = (s + alpha * slack_step(ls, r, s)) * (l + alpha * cx.ld_k(ls * ROWS + r));
+                    pmin = fmin(pmin, on ? pr : 1e300); psum += on ? pr : 0.0;
+                }
+            const double gmn = cx.gmin(pmin), gsm = cx.gsum(psum);
+            const bool ok = gmn >= 1e-3 * (gsm * minv);
+            if (!cx.any(running && !ok)) break;
+            if (!ok) alpha *= 0.7;
+        }
+        // ---- step
+        if (running) {
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++)
+                MPCX_UNROLL
+                for (int r = 0; r < ROWS; r++) {          // rows that are off have ds = dl = 0
+                    const double s = cx.ld_s(ls * ROWS + r);
+                    cx.st_s(ls * ROWS + r, s + alpha * slack_step(ls, r, s));
+                    cx.st_l(ls * ROWS + r, cx.ld_l(ls * ROWS + r) + alpha * cx.ld_k(ls * ROWS + r));
+                }
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) {
+                U0[ls] += alpha * D0[ls]; U1[ls] += alpha * D1[ls];
+                X0[ls] += alpha * E0[ls]; X1[ls] += alpha * E1[ls]; X2[ls] += alpha * E2[ls]; X3[ls] += alpha * E3[ls];
+            }
+            it++;
+        }
+    }
+#undef PX
+#undef WV
+#undef WP
+#undef RA_
+#undef RS_
+
+    // ------------------------------------------------------------------ outputs: u, x = rollout of the linear model
+    rollout(false, X0, X1, X2, X3);
+    if (valid) {
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++)
+            if (act[ls]) {
+                const int t = q * SPL + ls;
+                pb.u_out[t] = U0[ls]; pb.u_out[T + t] = U1[ls];
+                pb.x_out[0 * W + t + 1] = X0[ls]; pb.x_out[1 * W + t + 1] = X1[ls];
+                pb.x_out[2 * W + t + 1] = X2[ls]; pb.x_out[3 * W + t + 1] = X3[ls];
+            }
+        if (q == 0) {
+            pb.x_out[0] = x00; pb.x_out[W] = x01; pb.x_out[2 * W] = x02; pb.x_out[3 * W] = x03;
+            *pb.status = status; *pb.iters = it;
+            pb.kkt[0] = res_d; pb.kkt[1] = res_p; pb.kkt[2] = mu; pb.kkt[3] = 0.0;
+        }
+    }
+}
+
+}  // namespace mpcx_stage

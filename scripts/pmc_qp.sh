@@ -10,7 +10,7 @@ for d in ('a','b'):
     rows=list(csv.DictReader(open('$OUT/%s/p_counter_collection.csv'%d)))
     agg=collections.defaultdict(float); disp=set()
     for r in rows:
-        if 'qp_kernel' in r['Kernel_Name']:
+        if 'qp_' in r['Kernel_Name']:
             agg[r['Counter_Name']]+=float(r['Counter_Value']); disp.add(r['Dispatch_Id'])
     for k,v in sorted(agg.items()): print('%-26s %.4g'%(k,v/len(disp)))
 PY
