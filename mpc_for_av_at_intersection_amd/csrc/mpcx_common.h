@@ -47,7 +47,7 @@ struct QpArgs {
     int has_tune;                 // tune != NULL, tested on the host like has_warm
 };
 
-void launch_qp_stage(const QpArgs &a, hipStream_t st);   // mpcx_qp_quad.hip
+void launch_qp_stage(const QpArgs &a, hipStream_t st, int n_cu);   // mpcx_qp_quad.hip
 
 
 __device__ __forceinline__ double rdlane(double v, int l) {

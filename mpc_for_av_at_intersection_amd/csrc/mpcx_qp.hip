@@ -647,7 +647,7 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     // T <= 20: stage-structured solver, four lanes per problem (mpcx_qp_quad.hip); longer horizons (and MPCX_QP_KERNEL=wave):
     // the condensed solver of this file, one wavefront per problem
     static const bool force_wave = [] { const char *e = getenv("MPCX_QP_KERNEL"); return e && !strcmp(e, "wave"); }();
-    if (T <= 20 && !force_wave) mpcx::launch_qp_stage(a, ctx->stream);
+    if (T <= 20 && !force_wave) mpcx::launch_qp_stage(a, ctx->stream, ctx->n_cu);
     else if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream, grid);
     else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream, grid);
     else if (T <= 20) mpcx::launch_qp<20>(a, ctx->stream, grid);

@@ -41,6 +41,7 @@ struct GroupCx {
         return ((m >> (lane & ~(LQ - 1))) & ((1ull << LQ) - 1ull)) != 0ull;
     }
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
+    __device__ __forceinline__ int count(bool b) const { return __popcll(__ballot(b)); }       // lanes, not groups
     __device__ __forceinline__ double rcp(double v) const { return frcp(v); }
     __device__ __forceinline__ double rcp_fast(double v) const { return frcp1(v); }     // seed + one Newton step
     // ratio tests only: the hardware seed; the 0.995 step margin is four orders of magnitude wider than its error
@@ -55,53 +56,67 @@ struct GroupCx {
     __device__ __forceinline__ void st_k(int k, double v) { sh[(2 * SPL * 8 + k) * 64 + lane] = v; }
 };
 
+// work queue: group leaders draw problem indices from a global ticket until the batch is exhausted
+template <int LQ, int SPL, bool TUNED>
+struct QueueSrc {
+    const QpArgs &a;
+    __device__ __forceinline__ mpcx_mpc_params params() const { return a.p; }
+    __device__ __forceinline__ mpcx_stage::Problem at(int b) const {
+        const int T = a.p.T, W = T + 1;
+        return mpcx_stage::Problem{a.x0 + (size_t)b * 4, a.xref + (size_t)b * 4 * W, a.xbar + (size_t)b * 4 * W,
+                                   a.has_warm ? a.u_warm + (size_t)b * 2 * T : nullptr, a.re + (size_t)b * W,
+                                   a.x_out + (size_t)b * 4 * W, a.u_out + (size_t)b * 2 * T, a.kkt + (size_t)b * 4,
+                                   a.status + b, a.iters + b};
+    }
+    __device__ __forceinline__ mpcx_stage::Problem first() const { return at(0); }
+    // every round either advances some group's iteration counter or consumes a ticket
+#ifndef MPCX_REFILL_GROUPS
+#define MPCX_REFILL_GROUPS 2
+#endif
+    __device__ __forceinline__ int refill_min() const { return MPCX_REFILL_GROUPS * LQ; }   // in lanes
+    __device__ __forceinline__ long max_rounds() const { return ((long)a.B + 2) * (long)(a.p.max_iter + 4); }
+    __device__ __forceinline__ bool fetch(GroupCx<LQ, SPL> &cx, mpcx_mpc_params &P, mpcx_stage::Problem &pb) const {
+        int t = 0;
+        if (cx.q == 0) t = atomicAdd(a.ticket, 1);
+        t = (int)cx.gsum((double)t);                  // the other lanes contribute 0: everybody gets the leader's ticket
+        const bool have = t < a.B;
+        const int b = have ? t : 0;
+        pb = at(b);
+        if (TUNED) {
+            const mpcx_qp_tuning &tu = a.tune[b];
+            P.w_perp = tu.w_perp; P.w_para = tu.w_para;
+            P.R[0] = tu.R[0]; P.R[1] = tu.R[1]; P.Rd[0] = tu.Rd[0]; P.Rd[1] = tu.Rd[1];
+            P.Q_v_yaw[0] = tu.Q_v_yaw[0]; P.Q_v_yaw[1] = tu.Q_v_yaw[1];
+            P.Qf[0] = tu.Qf[0]; P.Qf[1] = tu.Qf[1]; P.Qf[2] = tu.Qf[2]; P.Qf[3] = tu.Qf[3];
+            P.max_accel = tu.max_accel; P.max_decel = tu.max_decel; P.max_dsteer = tu.max_dsteer;
+        }
+        return have;
+    }
+};
+
 template <int LQ, int SPL, bool TUNED>
 __global__ __launch_bounds__(64, 1) void qp_quad_kernel(QpArgs a) {
-    constexpr int PER_WAVE = 64 / LQ;
     __shared__ double sh[3 * SPL * 8 * 64];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x * PER_WAVE + lane / LQ;
-    const bool valid = b < a.B;
-    const int bc = valid ? b : 0;
-    mpcx_mpc_params P = a.p;
-    if (TUNED) {
-        const mpcx_qp_tuning &tu = a.tune[bc];
-        P.w_perp = tu.w_perp; P.w_para = tu.w_para;
-        P.R[0] = tu.R[0]; P.R[1] = tu.R[1]; P.Rd[0] = tu.Rd[0]; P.Rd[1] = tu.Rd[1];
-        P.Q_v_yaw[0] = tu.Q_v_yaw[0]; P.Q_v_yaw[1] = tu.Q_v_yaw[1];
-        P.Qf[0] = tu.Qf[0]; P.Qf[1] = tu.Qf[1]; P.Qf[2] = tu.Qf[2]; P.Qf[3] = tu.Qf[3];
-        P.max_accel = tu.max_accel; P.max_decel = tu.max_decel; P.max_dsteer = tu.max_dsteer;
-    }
-    const int T = a.p.T, W = T + 1;
-    mpcx_stage::Problem pb{a.x0 + (size_t)bc * 4, a.xref + (size_t)bc * 4 * W, a.xbar + (size_t)bc * 4 * W,
-                           a.has_warm ? a.u_warm + (size_t)bc * 2 * T : nullptr, a.re + (size_t)bc * W,
-                           a.x_out + (size_t)bc * 4 * W, a.u_out + (size_t)bc * 2 * T, a.kkt + (size_t)bc * 4,
-                           a.status + bc, a.iters + bc};
     GroupCx<LQ, SPL> cx{lane & (LQ - 1), lane, (lds_double *)sh};
-    mpcx_stage::solve(cx, P, pb, valid);
+    QueueSrc<LQ, SPL, TUNED> src{a};
+    mpcx_stage::solve_queue(cx, src);
 }
 
 template <int LQ, int SPL>
-void launch_qp_group(const QpArgs &a, hipStream_t st) {
+void launch_qp_group(const QpArgs &a, hipStream_t st, int n_cu) {
     const int per_wave = 64 / LQ;
-    const int grid = (a.B + per_wave - 1) / per_wave;
+    const int need = (a.B + per_wave - 1) / per_wave;
+    const int resident = n_cu * 4;                      // one wavefront per SIMD
+    const int grid = need < resident ? need : resident;
     if (a.has_tune) hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, true>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, false>), dim3(grid), dim3(64), 0, st, a);
 }
 
-void launch_qp_stage(const QpArgs &a, hipStream_t st) {
+void launch_qp_stage(const QpArgs &a, hipStream_t st, int n_cu) {
     const int T = a.p.T;
-#ifndef MPCX_LQ
-#define MPCX_LQ 8
-#endif
-#if MPCX_LQ == 4
-    if (T <= 12) launch_qp_group<4, 3>(a, st);
-    else if (T <= 16) launch_qp_group<4, 4>(a, st);
-    else launch_qp_group<4, 5>(a, st);
-#else
-    if (T <= 16) launch_qp_group<8, 2>(a, st);
-    else launch_qp_group<8, 3>(a, st);
-#endif
+    if (T <= 16) launch_qp_group<8, 2>(a, st, n_cu);
+    else launch_qp_group<8, 3>(a, st, n_cu);
 }
 
 }  // namespace mpcx

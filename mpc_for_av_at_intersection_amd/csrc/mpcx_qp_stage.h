@@ -42,57 +42,38 @@ struct Problem {            // one QP (pointers to that problem's rows of the ba
     int32_t *status, *iters;
 };
 
-template <class Cx>
-MPCX_HD void solve(Cx &cx, const mpcx_mpc_params &P, const Problem &pb, bool valid) {
+template <class Cx, class Src>
+MPCX_HD void solve_queue(Cx &cx, Src &src) {
     constexpr int LQ = Cx::LQ, SPL = Cx::SPL;
     const int q = cx.q;
+    mpcx_mpc_params P = src.params();       // weights / limits may be replaced per problem by fetch(); T, dt, L never change
+    Problem pb = src.first();
     const int T = P.T, W = T + 1;
     const double dt = P.dt;
     const double minv = 1.0 / (double)(8 * T - 2);
     const int NTURN = (T + SPL - 1) / SPL < LQ ? (T + SPL - 1) / SPL : LQ;   // lanes q >= NTURN own no stage of this horizon
+    bool have = false, drained = false;     // this group holds a problem / found the queue empty (uniform within a group)
 
     // ------------------------------------------------------------------ per-slot constants and iterate
-    double A0[SPL], A1[SPL], A2[SPL], A3[SPL], B3[SPL];       // a02, a03, a12, a13, b3 of mpc.py:58-79 (delta_bar = 0)
-    double Wxx[SPL], Wxy[SPL], Wyy[SPL];                      // 2*W_{t+1} xy block (mpc.py:157-170)
-    bool ended[SPL], uend[SPL];                               // x_{t+1} / u_t fall on the clipped tail of the reference (Qf / R_end)
-    double U0[SPL], U1[SPL];                                  // a_t, delta_t
+    double A0[SPL] = {}, A1[SPL] = {}, A2[SPL] = {}, A3[SPL] = {}, B3[SPL] = {};   // a02, a03, a12, a13, b3 of mpc.py:58-79 (delta_bar = 0)
+    double Wxx[SPL] = {}, Wxy[SPL] = {}, Wyy[SPL] = {};       // 2*W_{t+1} xy block (mpc.py:157-170)
+    bool ended[SPL] = {}, uend[SPL] = {};                     // x_{t+1} / u_t fall on the clipped tail of the reference (Qf / R_end)
+    double U0[SPL] = {}, U1[SPL] = {};                        // a_t, delta_t
     double X0[SPL] = {}, X1[SPL] = {}, X2[SPL] = {}, X3[SPL] = {};    // x_{t+1}
-    bool act[SPL], rate[SPL];
-    double PH[SPL];                                           // yaw of the linearisation point (for C_t)
-    const double x00 = valid ? pb.x0[0] : 0.0, x01 = valid ? pb.x0[1] : 0.0, x02 = valid ? pb.x0[2] : 0.0, x03 = valid ? pb.x0[3] : 0.0;
+    bool act[SPL] = {}, rate[SPL] = {};
+    double PH[SPL] = {};                                      // yaw of the linearisation point (for C_t)
+    double x00 = 0.0, x01 = 0.0, x02 = 0.0, x03 = 0.0;
+    double Rda = 0.0, Rds = 0.0, wv_run = 0.0, wp_run = 0.0, wv_end = 0.0, wp_end = 0.0;
+    double ra_run = 1.0, rs_run = 1.0, ra_end = 1.0, rs_end = 1.0, rmax = 0.0, hnorm = 1.0, gnorm = 1.0, tol_loose = 1e-7;
+    int status = MPCX_QP_MAXITER, it = 0, loose_run = 0, max_iter = -1;
+    double res_d = 0.0, res_p = 0.0, mu = 0.0;
+    bool loose = false, running = false;    // uniform within a group; other groups of the wave may be in another state
 
-    MPCX_UNROLL
-    for (int ls = 0; ls < SPL; ls++) {
-        const int t = q * SPL + ls;
-        act[ls] = valid && t < T;
-        rate[ls] = act[ls] && t >= 1;
-        const int tc = act[ls] ? t : 0;
-        const double vb = act[ls] ? pb.xbar[2 * W + tc] : 0.0, ph = act[ls] ? pb.xbar[3 * W + tc] : 0.0;
-        double sn, cs;
-        sincos(ph, &sn, &cs);
-        A0[ls] = dt * cs; A1[ls] = -dt * vb * sn; A2[ls] = dt * sn; A3[ls] = dt * vb * cs; B3[ls] = dt * vb / P.L;
-        ended[ls] = act[ls] ? (pb.re[tc + 1] != 0) : false;
-        const double yr = act[ls] ? pb.xref[3 * W + tc + 1] : 0.0;
-        sincos(yr, &sn, &cs);
-        // perpendicular projector [[s^2, -sc], [-sc, c^2]] * w_perp + parallel projector [[c^2, cs], [cs, s^2]] * w_para
-        Wxx[ls] = 2.0 * (ended[ls] ? P.Qf[0] : (sn * sn) * P.w_perp + (cs * cs) * P.w_para);
-        Wxy[ls] = 2.0 * (ended[ls] ? 0.0 : (-sn * cs) * P.w_perp + (cs * sn) * P.w_para);
-        Wyy[ls] = 2.0 * (ended[ls] ? P.Qf[1] : (cs * cs) * P.w_perp + (sn * sn) * P.w_para);
-        uend[ls] = act[ls] ? (pb.re[tc] != 0) : false;
-        U0[ls] = (act[ls] && pb.u_warm) ? pb.u_warm[tc] : 0.0;
-        U1[ls] = (act[ls] && pb.u_warm) ? pb.u_warm[T + tc] : 0.0;
-        // slots beyond the horizon (and groups beyond the batch) carry all-zero data: every sweep below passes through them
-        // unchanged (zero dynamics, zero weights, rows off), so the code needs no per-slot branches
-        if (!act[ls]) { A0[ls] = A1[ls] = A2[ls] = A3[ls] = B3[ls] = 0.0; Wxx[ls] = Wxy[ls] = Wyy[ls] = 0.0; }
-        PH[ls] = ph;
-    }
-    const double Rda = 2.0 * P.Rd[0], Rds = 2.0 * P.Rd[1];
-    const double wv_run = 2.0 * P.Q_v_yaw[0], wp_run = 2.0 * P.Q_v_yaw[1], wv_end = 2.0 * P.Qf[2], wp_end = 2.0 * P.Qf[3];
-    const double ra_run = 2.0 * P.R[0], rs_run = 2.0 * P.R[1], ra_end = 2.0 * P.R_end[0], rs_end = 2.0 * P.R_end[1];
 #define WV(ls) (act[ls] ? (ended[ls] ? wv_end : wv_run) : 0.0)
 #define WP(ls) (act[ls] ? (ended[ls] ? wp_end : wp_run) : 0.0)
 #define RA_(ls) (uend[ls] ? ra_end : ra_run)
 #define RS_(ls) (uend[ls] ? rs_end : rs_run)
+
 
     // ---- serial sweeps are written as "turns": lane `turn` works on its slots, then hands its carry to the neighbour
     // forward rollout of the linear model from (u0, u1): fills (X0..X3); `free` = true uses u = 0 (free response)
@@ -158,33 +139,6 @@ MPCX_HD void solve(Cx &cx, const mpcx_mpc_params &P, const Problem &pb, bool val
         for (int ls = 0; ls + 1 < SPL; ls++) O[ls] = V[ls + 1];
     };
 
-    // ------------------------------------------------------------------ scaling norms, initial point (same rules as the condensed solver)
-    int status = MPCX_QP_MAXITER, it = 0;
-    double res_d = 0.0, res_p = 0.0, mu = 0.0;
-    const bool feasible0 = !(x02 > P.max_speed + 1e-9 || x02 < P.min_speed - 1e-9);
-    double gnorm = 1.0;
-    {
-        double F0[SPL] = {}, F1[SPL] = {}, F2[SPL] = {}, F3[SPL] = {}, Q0[SPL], Q1[SPL], Q2[SPL], Q3[SPL], Z[SPL], O0[SPL] = {}, O1[SPL] = {};
-        rollout(true, F0, F1, F2, F3);
-        MPCX_UNROLL
-        for (int ls = 0; ls < SPL; ls++) {
-            const int t = q * SPL + ls;
-            const int tc = t + 1 <= T ? t + 1 : T;        // slots beyond the horizon read a valid column; their weights are zero
-            const double e0 = F0[ls] - pb.xref[0 * W + tc], e1 = F1[ls] - pb.xref[1 * W + tc];
-            const double e2 = F2[ls] - pb.xref[2 * W + tc], e3 = F3[ls] - pb.xref[3 * W + tc];
-            Q0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; Q1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; Q2[ls] = WV(ls) * e2; Q3[ls] = WP(ls) * e3;
-            Z[ls] = 0.0;
-        }
-        costate(Q0, Q1, Q2, Q3, Z, Z, O0, O1);
-        double gm = 0.0;
-        MPCX_UNROLL
-        for (int ls = 0; ls < SPL; ls++) gm = fmax(gm, fmax(fabs(O0[ls]), fabs(O1[ls])));
-        gnorm = fmax(1.0, cx.gmax(gm));
-    }
-    const double rmax = P.max_dsteer * dt;
-    const double hnorm = fmax(fmax(fmax(1.0, fabs(P.max_accel)), fmax(fabs(P.max_decel), fabs(P.max_steer))),
-                              fmax(fabs(rmax), fmax(fabs(P.max_speed - x02), fabs(x02 - P.min_speed))));
-    rollout(false, X0, X1, X2, X3);
     // rows: residual of row r at the current iterate WITHOUT the slack: g_r(u, x) - h_r
     double Dprev[SPL];
     auto row_gap = [&](int ls, int r, double dprev) -> double {
@@ -200,16 +154,6 @@ MPCX_HD void solve(Cx &cx, const mpcx_mpc_params &P, const Problem &pb, bool val
         }
     };
     auto row_on = [&](int ls, int r) -> bool { return (r == 4 || r == 5) ? rate[ls] : act[ls]; };
-    prev_of(U1, Dprev);
-    MPCX_UNROLL
-    for (int ls = 0; ls < SPL; ls++)
-        MPCX_UNROLL
-        for (int r = 0; r < ROWS; r++) {
-            const double si = -row_gap(ls, r, Dprev[ls]);
-            cx.st_s(ls * ROWS + r, row_on(ls, r) ? (si > 0.5 ? si : 0.5) : 1.0);
-            cx.st_l(ls * ROWS + r, row_on(ls, r) ? 1.0 : 0.0);
-        }
-
     // gradient of the cost (no multipliers) wrt x_{t+1} and u_t at the current iterate; recomputed where needed rather than
     // kept across the Riccati sweep (30 doubles per lane that the sweep needs for the cost-to-go)
     auto cost_grad = [&](double (&G0)[SPL], double (&G1)[SPL], double (&G2)[SPL], double (&G3)[SPL], double (&H0)[SPL], double (&H1)[SPL]) {
@@ -230,18 +174,120 @@ MPCX_HD void solve(Cx &cx, const mpcx_mpc_params &P, const Problem &pb, bool val
         }
     };
 
-    const double tol_loose = P.tol > 1e-7 ? P.tol : 1e-7;
-    int loose_run = 0;
-    bool loose = false;
-    const int max_iter = (valid && feasible0) ? P.max_iter : -1;
-    if (!feasible0) status = MPCX_QP_INFEASIBLE;
-    bool running = valid && feasible0;      // uniform within a group; other groups of the wave may still be running
+    // ------------------------------------------------------------------ a new problem enters the group: constants, scaling norms,
+    // initial point (same rules as the condensed solver).  With have == false everything is zeroed, so the group idles harmlessly.
+    auto setup = [&]() {
+        const bool valid = have;
+        x00 = valid ? pb.x0[0] : 0.0; x01 = valid ? pb.x0[1] : 0.0; x02 = valid ? pb.x0[2] : 0.0; x03 = valid ? pb.x0[3] : 0.0;
+    
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++) {
+            const int t = q * SPL + ls;
+            act[ls] = valid && t < T;
+            rate[ls] = act[ls] && t >= 1;
+            const int tc = act[ls] ? t : 0;
+            const double vb = act[ls] ? pb.xbar[2 * W + tc] : 0.0, ph = act[ls] ? pb.xbar[3 * W + tc] : 0.0;
+            double sn, cs;
+            sincos(ph, &sn, &cs);
+            A0[ls] = dt * cs; A1[ls] = -dt * vb * sn; A2[ls] = dt * sn; A3[ls] = dt * vb * cs; B3[ls] = dt * vb / P.L;
+            ended[ls] = act[ls] ? (pb.re[tc + 1] != 0) : false;
+            const double yr = act[ls] ? pb.xref[3 * W + tc + 1] : 0.0;
+            sincos(yr, &sn, &cs);
+            // perpendicular projector [[s^2, -sc], [-sc, c^2]] * w_perp + parallel projector [[c^2, cs], [cs, s^2]] * w_para
+            Wxx[ls] = 2.0 * (ended[ls] ? P.Qf[0] : (sn * sn) * P.w_perp + (cs * cs) * P.w_para);
+            Wxy[ls] = 2.0 * (ended[ls] ? 0.0 : (-sn * cs) * P.w_perp + (cs * sn) * P.w_para);
+            Wyy[ls] = 2.0 * (ended[ls] ? P.Qf[1] : (cs * cs) * P.w_perp + (sn * sn) * P.w_para);
+            uend[ls] = act[ls] ? (pb.re[tc] != 0) : false;
+            U0[ls] = (act[ls] && pb.u_warm) ? pb.u_warm[tc] : 0.0;
+            U1[ls] = (act[ls] && pb.u_warm) ? pb.u_warm[T + tc] : 0.0;
+            // slots beyond the horizon (and groups beyond the batch) carry all-zero data: every sweep below passes through them
+            // unchanged (zero dynamics, zero weights, rows off), so the code needs no per-slot branches
+            if (!act[ls]) { A0[ls] = A1[ls] = A2[ls] = A3[ls] = B3[ls] = 0.0; Wxx[ls] = Wxy[ls] = Wyy[ls] = 0.0; }
+            PH[ls] = ph;
+        }
+        Rda = 2.0 * P.Rd[0]; Rds = 2.0 * P.Rd[1];
+        wv_run = 2.0 * P.Q_v_yaw[0]; wp_run = 2.0 * P.Q_v_yaw[1]; wv_end = 2.0 * P.Qf[2]; wp_end = 2.0 * P.Qf[3];
+        ra_run = 2.0 * P.R[0]; rs_run = 2.0 * P.R[1]; ra_end = 2.0 * P.R_end[0]; rs_end = 2.0 * P.R_end[1];
+        status = MPCX_QP_MAXITER; it = 0;
+        res_d = 0.0; res_p = 0.0; mu = 0.0;
+        const bool feasible0 = !(x02 > P.max_speed + 1e-9 || x02 < P.min_speed - 1e-9);
+        gnorm = 1.0;
+        {
+            double F0[SPL] = {}, F1[SPL] = {}, F2[SPL] = {}, F3[SPL] = {}, Q0[SPL], Q1[SPL], Q2[SPL], Q3[SPL], Z[SPL], O0[SPL] = {}, O1[SPL] = {};
+            rollout(true, F0, F1, F2, F3);
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) {
+                const int t = q * SPL + ls;
+                const int tc = t + 1 <= T ? t + 1 : T;        // slots beyond the horizon read a valid column; their weights are zero
+                const double e0 = F0[ls] - pb.xref[0 * W + tc], e1 = F1[ls] - pb.xref[1 * W + tc];
+                const double e2 = F2[ls] - pb.xref[2 * W + tc], e3 = F3[ls] - pb.xref[3 * W + tc];
+                Q0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; Q1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; Q2[ls] = WV(ls) * e2; Q3[ls] = WP(ls) * e3;
+                Z[ls] = 0.0;
+            }
+            costate(Q0, Q1, Q2, Q3, Z, Z, O0, O1);
+            double gm = 0.0;
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) gm = fmax(gm, fmax(fabs(O0[ls]), fabs(O1[ls])));
+            gnorm = fmax(1.0, cx.gmax(gm));
+        }
+        rmax = P.max_dsteer * dt;
+        hnorm = fmax(fmax(fmax(1.0, fabs(P.max_accel)), fmax(fabs(P.max_decel), fabs(P.max_steer))),
+                                  fmax(fabs(rmax), fmax(fabs(P.max_speed - x02), fabs(x02 - P.min_speed))));
+        rollout(false, X0, X1, X2, X3);
+        prev_of(U1, Dprev);
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++)
+            MPCX_UNROLL
+            for (int r = 0; r < ROWS; r++) {
+                const double si = -row_gap(ls, r, Dprev[ls]);
+                cx.st_s(ls * ROWS + r, row_on(ls, r) ? (si > 0.5 ? si : 0.5) : 1.0);
+                cx.st_l(ls * ROWS + r, row_on(ls, r) ? 1.0 : 0.0);
+            }
+    
+        tol_loose = P.tol > 1e-7 ? P.tol : 1e-7;
+        loose_run = 0; loose = false;
+        max_iter = (valid && feasible0) ? P.max_iter : -1;
+        if (!feasible0) status = MPCX_QP_INFEASIBLE;
+        running = valid && feasible0;
+    };
+    // ------------------------------------------------------------------ a finished problem leaves: u, x = rollout of the linear model
+    auto emit = [&]() {
+        rollout(false, X0, X1, X2, X3);
+        {
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++)
+                if (act[ls]) {
+                    const int t = q * SPL + ls;
+                    pb.u_out[t] = U0[ls]; pb.u_out[T + t] = U1[ls];
+                    pb.x_out[0 * W + t + 1] = X0[ls]; pb.x_out[1 * W + t + 1] = X1[ls];
+                    pb.x_out[2 * W + t + 1] = X2[ls]; pb.x_out[3 * W + t + 1] = X3[ls];
+                }
+            if (q == 0) {
+                pb.x_out[0] = x00; pb.x_out[W] = x01; pb.x_out[2 * W] = x02; pb.x_out[3 * W] = x03;
+                *pb.status = status; *pb.iters = it;
+                pb.kkt[0] = res_d; pb.kkt[1] = res_p; pb.kkt[2] = mu; pb.kkt[3] = 0.0;
+            }
+        }
+    };
 
-    // ------------------------------------------------------------------ iterations
-    // `cx.any(running)` keeps every lane of the wavefront in the loop until all its groups are done (cross-lane
-    // operations need all lanes); a finished group keeps computing on frozen data and discards the results.
-    for (int guard = 0; guard <= P.max_iter + 1; guard++) {
-        if (!cx.any(running)) break;
+    // ------------------------------------------------------------------ main loop: one interior-point iteration per round for every group
+    // that is running; a group that is not (finished, or never started) first hands in its solution and draws the next
+    // problem.  `cx.any` keeps the wavefront together (cross-lane operations need every lane in the loop); the loop is
+    // bounded by construction: each round either advances an iteration counter or consumes a ticket.
+    const long rounds = src.max_rounds();
+    for (long guard = 0; guard < rounds; guard++) {
+        const bool need = !running && !drained;
+        // hand-in / draw / set-up costs the whole wavefront a few thousand instructions: do it when at least `refill_min`
+        // groups are waiting, or when nobody is running any more
+        if (cx.count(need) >= src.refill_min() || (cx.any(need) && !cx.any(running))) {
+            if (need) {                  // uniform within a group: the DPP operations inside stay inside the group
+                if (have) emit();
+                have = src.fetch(cx, P, pb);
+                drained = !have;         // the queue is empty: zero the group's data once and idle from now on
+                setup();
+            }
+        }
+        if (!cx.any(have)) break;
         // ---- local pass A: rows, complementarity, gradient pieces
         prev_of(U1, Dprev);
         double DSa[SPL], DSd[SPL], DSr[SPL], DSv[SPL];  // barrier weights d = lam/s summed over the row pairs
@@ -609,24 +655,6 @@ MPCX_HD void solve(Cx &cx, const mpcx_mpc_params &P, const Problem &pb, bool val
 #undef WP
 #undef RA_
 #undef RS_
-
-    // ------------------------------------------------------------------ outputs: u, x = rollout of the linear model
-    rollout(false, X0, X1, X2, X3);
-    if (valid) {
-        MPCX_UNROLL
-        for (int ls = 0; ls < SPL; ls++)
-            if (act[ls]) {
-                const int t = q * SPL + ls;
-                pb.u_out[t] = U0[ls]; pb.u_out[T + t] = U1[ls];
-                pb.x_out[0 * W + t + 1] = X0[ls]; pb.x_out[1 * W + t + 1] = X1[ls];
-                pb.x_out[2 * W + t + 1] = X2[ls]; pb.x_out[3 * W + t + 1] = X3[ls];
-            }
-        if (q == 0) {
-            pb.x_out[0] = x00; pb.x_out[W] = x01; pb.x_out[2 * W] = x02; pb.x_out[3 * W] = x03;
-            *pb.status = status; *pb.iters = it;
-            pb.kkt[0] = res_d; pb.kkt[1] = res_p; pb.kkt[2] = mu; pb.kkt[3] = 0.0;
-        }
-    }
 }
 
 }  // namespace mpcx_stage

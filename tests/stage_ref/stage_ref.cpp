@@ -16,6 +16,7 @@ struct HostCx {
     double gsum(double v) const { return v; }
     bool gany(bool b) const { return b; }
     bool any(bool b) const { return b; }
+    int count(bool b) const { return b ? 1 : 0; }
     double rcp(double v) const { return 1.0 / v; }
     double rcp_fast(double v) const { return 1.0 / v; }
     double rcp_seed(double v) const { return 1.0 / v; }
@@ -29,13 +30,27 @@ struct HostCx {
 };
 }  // namespace
 
+namespace {
+struct HostSrc {            // a queue of exactly one problem
+    const mpcx_mpc_params *p;
+    mpcx_stage::Problem pb;
+    int taken = 0;
+    mpcx_mpc_params params() const { return *p; }
+    mpcx_stage::Problem first() const { return pb; }
+    long max_rounds() const { return p->max_iter + 4; }
+    int refill_min() const { return 1; }
+    bool fetch(HostCx &, mpcx_mpc_params &, mpcx_stage::Problem &out) { out = pb; return taken++ == 0; }
+};
+}  // namespace
+
 extern "C" int stage_ref_solve(const mpcx_mpc_params *p, const double *x0, const double *xref, const double *xbar,
                                const uint8_t *re, const double *u_warm, double *x_out, double *u_out, int32_t *status,
                                int32_t *iters, double *kkt) {
     HostCx cx;
     memset(cx.s, 0, sizeof cx.s); memset(cx.l, 0, sizeof cx.l); memset(cx.k, 0, sizeof cx.k);
     mpcx_stage::Problem pb{x0, xref, xbar, u_warm, re, x_out, u_out, kkt, status, iters};
-    mpcx_stage::solve(cx, *p, pb, true);
+    HostSrc src{p, pb};
+    mpcx_stage::solve_queue(cx, src);
     return 0;
 }
 
