@@ -37,7 +37,7 @@ def agent_step_bytes(T: int, A: int) -> float:
     return 32 + 16 * T + 48 * (A - 1) + 24 * (T + 1) + 32 * (T + 1) + 16 * T + 8
 
 
-def pmc_traffic_bytes(kernel='qp_kernel'):
+def pmc_traffic_bytes(kernel='qp_'):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/r01_pmc_final.csv;
     bench.py cannot run the profiler on itself): 2 x FETCH_SIZE (gfx950 under-reports reads by 2x, MI355X_MICROARCH.md
     'HBM') + WRITE_SIZE, KiB -> bytes. None when the file is absent."""
@@ -183,10 +183,11 @@ def main():
                          'frac': achieved_tf / FP64_PEAK_TFLOPS,
                          'traffic': pmc_traffic_bytes() if (args.horizon == 20 and args.batch == 4096 and args.agents == 8) else None,
                          'traffic_note': 'HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (profiles/r01_pmc_final.csv), same workload; algorithmic bytes per launch = %.3g' % (P * (32 + 2 * 32 * (args.horizon + 1) + (args.horizon + 1) + 16 * args.horizon + 32 * (args.horizon + 1) + 16 * args.horizon + 40)),
-                         'kernel': 'qp_kernel<%d>' % args.horizon,
+                         'kernel': ('qp_quad_kernel<8,%d> (stage-structured IPM, 8 lanes per QP)' % (2 if args.horizon <= 16 else 3)) if (args.horizon <= 20 and os.environ.get('MPCX_QP_KERNEL') != 'wave') else 'qp_kernel<%d> (condensed IPM, one wavefront per QP)' % args.horizon,
                          'kernel_ms': qp_ms, 'kernel_launches_timed': qp_launches, 'flops_per_qp': qp_flops(args.horizon, mean_iters),
-                         'note': 'FP64 compute bound (MI355X FP64 matrix rate == FP64 vector rate, 78.6 TFLOP/s); algorithmic flops of '
-                                 'SURVEY 8(d) x measured mean IPM iterations / HIP-event kernel time; Hessian build on v_mfma_f64_16x16x4, factorisation and IPM on FP64 VALU'},
+                         'note': 'FP64 compute roof (MI355X FP64 matrix rate == FP64 vector rate, 78.6 TFLOP/s); achieved = algorithmic flops of '
+                                 'SURVEY 8(d) (condensed, structure-exploiting count) x measured mean IPM iterations / HIP-event kernel time. The '
+                                 'stage-structured kernel executes about 0.7x that count (Riccati sweeps are O(T)), all on the FP64 VALU'},
             'roofline_hbm': {'bound': 'hbm', 'achieved': bytes_step / (1e-3 * elapsed / args.steps * 1e3) / 1e9 * 1e3 / 1e3,
                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'note': 'algorithmic bytes per whole step / step time; not the binding roof'},
         }
