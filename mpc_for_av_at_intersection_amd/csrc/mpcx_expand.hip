@@ -8,12 +8,14 @@
 // Row order inside an obstacle is kept (axis-aligned rows come first for both boxes and the circle octagons,
 // obstacles.py:87-90,140-148), so the per-point early-out acts as an exact bounding-box cull.
 #include "mpcx_common.h"
+#include <cmath>
 #include <vector>
 
 struct mpcx_search_model {
     int n_prim, n_obst, n_pts, n_rows;
     int32_t *d_tmpl_off, *d_hp_off;
     double *d_tmpl_xy, *d_last_pose, *d_edge_cost, *d_hp;
+    double *d_aabb;     // per obstacle (xlo, xhi, ylo, yhi) implied by its rows of the form (+-1, 0, c) / (0, +-1, c); +-inf if none
 };
 
 namespace mpcx {
@@ -25,7 +27,7 @@ constexpr int EXP_MAX_OBST = 128;
 struct ExpandArgs {
     int n_prim, n_obst, n_pts, n_rows, n_nodes;
     const int32_t *tmpl_off, *hp_off;
-    const double *tmpl_xy, *last_pose, *edge_cost, *hp, *nodes, *nodes_cs;
+    const double *tmpl_xy, *last_pose, *edge_cost, *hp, *aabb, *nodes, *nodes_cs;
     double *nbr, *cost;
     uint8_t *collide;
 };
@@ -45,6 +47,8 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) {
     __shared__ double s_xy[EXP_MAX_PTS * 2];
     __shared__ int32_t s_hoff[EXP_MAX_OBST + 1];
     __shared__ int32_t s_toff[MPCX_MAX_PRIM + 1];
+    __shared__ double s_aabb[EXP_MAX_OBST * 4];
+    for (int i = threadIdx.x; i < a.n_obst * 4; i += blockDim.x) s_aabb[i] = a.aabb[i];
     for (int i = threadIdx.x; i < a.n_rows * 3; i += blockDim.x) s_hp[i] = a.hp[i];
     for (int i = threadIdx.x; i < a.n_pts * 2; i += blockDim.x) s_xy[i] = a.tmpl_xy[i];
     for (int i = threadIdx.x; i <= a.n_obst; i += blockDim.x) s_hoff[i] = a.hp_off[i];
@@ -62,10 +66,21 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) {
     const bool rot_only = (x == 0.0 && y == 0.0);     // linalg.py:13-17
     const double tx = rot_only ? 0.0 : x, ty = rot_only ? 0.0 : y;
 
-    // world-space collision points of this primitive (<= 32 kept in registers would spill; recompute per obstacle)
+    // world-space collision points of this primitive: first their bounding box, then, per obstacle, an EXACT cull -- a row
+    // (1, 0, c) is evaluated below as fl(wx + c) <= 0, which holds iff wx <= -c (a sum of two doubles is never rounded to
+    // zero), so "every point has wx > -c" proves that no point passes that row; likewise for (-1, 0, c), (0, +-1, c).  Only
+    // obstacles whose axis-aligned rows the box reaches run the per-point test (same arithmetic as before).
     const int p0 = s_toff[k], p1 = s_toff[k + 1];
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int i = p0; i < p1; i++) {
+        const double px = s_xy[2 * i], py = s_xy[2 * i + 1];
+        const double wx = __dadd_rn(fma(py, -s, __dmul_rn(px, c)), tx);
+        const double wy = __dadd_rn(fma(py, c, __dmul_rn(px, s)), ty);
+        xmin = fmin(xmin, wx); xmax = fmax(xmax, wx); ymin = fmin(ymin, wy); ymax = fmax(ymax, wy);
+    }
     bool hit = false;
     for (int o = 0; o < a.n_obst && !hit; o++) {
+        if (xmin > s_aabb[4 * o + 1] || xmax < s_aabb[4 * o] || ymin > s_aabb[4 * o + 3] || ymax < s_aabb[4 * o + 2]) continue;
         const int r0 = s_hoff[o], r1 = s_hoff[o + 1];
         for (int i = p0; i < p1 && !hit; i++) {
             const double px = s_xy[2 * i], py = s_xy[2 * i + 1];
@@ -123,7 +138,22 @@ extern "C" mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_
     m->d_last_pose = to_device(last_pose, (size_t)n_prim * 3);
     m->d_edge_cost = to_device(edge_cost, n_prim);
     m->d_hp = to_device(hp, (size_t)n_rows * 3);
-    if (!m->d_tmpl_off || !m->d_hp_off || !m->d_tmpl_xy || !m->d_last_pose || !m->d_edge_cost || !m->d_hp) {
+    {
+        std::vector<double> box((size_t)(n_obst ? n_obst : 1) * 4);
+        for (int o = 0; o < n_obst; o++) {
+            double xlo = -INFINITY, xhi = INFINITY, ylo = -INFINITY, yhi = INFINITY;
+            for (int r = hp_off[o]; r < hp_off[o + 1]; r++) {
+                const double ra = hp[3 * r], rb = hp[3 * r + 1], rc = hp[3 * r + 2];
+                if (ra == 1.0 && rb == 0.0) xhi = fmin(xhi, -rc);
+                else if (ra == -1.0 && rb == 0.0) xlo = fmax(xlo, rc);
+                else if (ra == 0.0 && rb == 1.0) yhi = fmin(yhi, -rc);
+                else if (ra == 0.0 && rb == -1.0) ylo = fmax(ylo, rc);
+            }
+            box[4 * o] = xlo; box[4 * o + 1] = xhi; box[4 * o + 2] = ylo; box[4 * o + 3] = yhi;
+        }
+        m->d_aabb = to_device(box.data(), box.size());
+    }
+    if (!m->d_tmpl_off || !m->d_hp_off || !m->d_tmpl_xy || !m->d_last_pose || !m->d_edge_cost || !m->d_hp || !m->d_aabb) {
         mpcx_fail(ctx, MPCX_E_LAUNCH, "search_model_create: device allocation failed");
         mpcx_search_model_destroy(m);
         return nullptr;
@@ -134,7 +164,7 @@ extern "C" mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_
 extern "C" void mpcx_search_model_destroy(mpcx_search_model *m) {
     if (!m) return;
     (void)hipFree(m->d_tmpl_off); (void)hipFree(m->d_hp_off); (void)hipFree(m->d_tmpl_xy);
-    (void)hipFree(m->d_last_pose); (void)hipFree(m->d_edge_cost); (void)hipFree(m->d_hp);
+    (void)hipFree(m->d_last_pose); (void)hipFree(m->d_edge_cost); (void)hipFree(m->d_hp); (void)hipFree(m->d_aabb);
     delete m;
 }
 
@@ -146,7 +176,7 @@ extern "C" int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, 
         return mpcx_fail(ctx, MPCX_E_INVALID, "expand_batch: null pointer or negative node count");
     if (n_nodes == 0) return MPCX_OK;
     mpcx::ExpandArgs a{m->n_prim, m->n_obst, m->n_pts, m->n_rows, n_nodes, m->d_tmpl_off, m->d_hp_off,
-                       m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_hp, nodes, nodes_cs, nbr, cost, collide};
+                       m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_hp, m->d_aabb, nodes, nodes_cs, nbr, cost, collide};
     const long long total = (long long)n_nodes * m->n_prim;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(mpcx::expand_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
