@@ -48,6 +48,13 @@ struct GroupCx {
     __device__ __forceinline__ double rcp_seed(double v) const { return __builtin_amdgcn_rcp(v); }
     // phase boundary: LDS values are re-read afterwards instead of being carried in registers across the phase
     __device__ __forceinline__ void fence() const { asm volatile("" ::: "memory"); }
+#ifdef MPCX_STAGE_PROFILE
+    // dev build: shader-clock time per phase, summed per wavefront (lane 0 adds to prof[phase] at the end)
+    unsigned long long t_last = 0, t_acc[10] = {};
+    __device__ __forceinline__ void stamp(int k) { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (t_last) t_acc[k] += t - t_last; t_last = t; }
+#else
+    __device__ __forceinline__ void stamp(int) const {}
+#endif
     __device__ __forceinline__ double ld_s(int k) const { return sh[(0 * SPL * 8 + k) * 64 + lane]; }
     __device__ __forceinline__ double ld_l(int k) const { return sh[(1 * SPL * 8 + k) * 64 + lane]; }
     __device__ __forceinline__ double ld_k(int k) const { return sh[(2 * SPL * 8 + k) * 64 + lane]; }
@@ -101,6 +108,9 @@ __global__ __launch_bounds__(64, 1) void qp_quad_kernel(QpArgs a) {
     GroupCx<LQ, SPL> cx{lane & (LQ - 1), lane, (lds_double *)sh};
     QueueSrc<LQ, SPL, TUNED> src{a};
     mpcx_stage::solve_queue(cx, src);
+#ifdef MPCX_STAGE_PROFILE
+    if (lane == 0) for (int k = 0; k < 10; k++) atomicAdd((unsigned long long *)(a.kkt + 4 * (size_t)a.B) + k, cx.t_acc[k]);   // dev build only: needs 10 spare slots behind kkt
+#endif
 }
 
 template <int LQ, int SPL>

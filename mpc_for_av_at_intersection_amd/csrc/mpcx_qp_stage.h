@@ -97,7 +97,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
             if (turn + 1 < NTURN) {
                 const double t0 = cx.prv(c0), t1 = cx.prv(c1), t2 = cx.prv(c2), t3 = cx.prv(c3);
-                if (q == turn + 1) { c0 = t0; c1 = t1; c2 = t2; c3 = t3; }
+                c0 = t0; c1 = t1; c2 = t2; c3 = t3;      // every lane shifts: only the lane whose turn comes next uses what it got
             }
         }
     };
@@ -120,7 +120,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
             if (turn > 0) {
                 const double t0 = cx.nxt(p0), t1 = cx.nxt(p1), t2 = cx.nxt(p2), t3 = cx.nxt(p3);
-                if (q == turn - 1) { p0 = t0; p1 = t1; p2 = t2; p3 = t3; }
+                p0 = t0; p1 = t1; p2 = t2; p3 = t3;
             }
         }
     };
@@ -288,6 +288,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
         }
         if (!cx.any(have)) break;
+        cx.stamp(0);                    // [refill / set-up]
         // ---- local pass A: rows, complementarity, gradient pieces
         prev_of(U1, Dprev);
         double DSa[SPL], DSd[SPL], DSr[SPL], DSv[SPL];  // barrier weights d = lam/s summed over the row pairs
@@ -317,6 +318,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         }
         double L45n[SPL], N45n[SPL];
         next_of(L45, L45n); next_of(N45, N45n);
+        cx.stamp(1);                    // [local pass A]
         // ---- dual residual: costate sweep with the multipliers
         double O0[SPL] = {}, O1[SPL] = {};
         {
@@ -341,6 +343,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         for (int ls = 0; ls < SPL; ls++) rd_m = fmax(rd_m, fmax(fabs(O0[ls]), fabs(O1[ls])));
         const double n_rd = cx.gmax(rd_m), n_rp = cx.gmax(rp_m), n_mu = cx.gsum(mu_s) * minv;
         if (running) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
+        cx.stamp(2);                    // [costate sweep]
         // ---- exit tests (uniform per group)
         if (running) {
             if (res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol) { status = MPCX_QP_OPTIMAL; running = false; }
@@ -449,9 +452,9 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 }
                 if (turn > 0) {
                     MPCX_UNROLL
-                    for (int i = 0; i < 21; i++) { const double tv = cx.nxt(Pm[i]); if (q == turn - 1) Pm[i] = tv; }
+                    for (int i = 0; i < 21; i++) Pm[i] = cx.nxt(Pm[i]);       // every lane shifts; lanes that had their turn no longer need theirs
                     MPCX_UNROLL
-                    for (int i = 0; i < 6; i++) { const double tv = cx.nxt(pv[i]); if (q == turn - 1) pv[i] = tv; }
+                    for (int i = 0; i < 6; i++) pv[i] = cx.nxt(pv[i]);
                 }
             }
         }
@@ -485,7 +488,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 }
                 if (turn + 1 < NTURN) {
                     MPCX_UNROLL
-                    for (int i = 0; i < 6; i++) { const double tv = cx.prv(z[i]); if (q == turn + 1) z[i] = tv; }
+                    for (int i = 0; i < 6; i++) z[i] = cx.prv(z[i]);
                 }
             }
         };
@@ -504,9 +507,11 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         };
 
         cx.fence();
+        cx.stamp(3);                    // [Riccati sweep]
         // ---- predictor direction, affine step length, centring parameter
         double DA0[SPL] = {}, DA1[SPL] = {}, EA0[SPL] = {}, EA1[SPL] = {}, EA2[SPL] = {}, EA3[SPL] = {}, DAp[SPL];
         forward(KA0, KA1, DA0, DA1, EA0, EA1, EA2, EA3);
+        cx.stamp(4);                    // [forward sweep 1]
         prev_of(DA1, DAp);
         double al = 1.0, c1 = 0.0, c2 = 0.0;
         // per row, recomputed from (s, lam, u, x) wherever needed instead of being kept: rp = s + gap, d = lam / s
@@ -534,6 +539,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         const double smu = sigma * n_mu;
 
         cx.fence();
+        cx.stamp(5);                    // [local pass C]
         // ---- corrector: nu = (lam rp - alpha_aff dsa dla + sigma mu) / s ; backward vector sweep with the stored gains
         double KC0[SPL] = {}, KC1[SPL] = {};
         double RC[SPL][ROWS];           // rc / s of the corrector (kept in registers across the two corrector sweeps)
@@ -585,12 +591,14 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 }
                 if (turn > 0) {
                     MPCX_UNROLL
-                    for (int i = 0; i < 6; i++) { const double tv = cx.nxt(pv[i]); if (q == turn - 1) pv[i] = tv; }
+                    for (int i = 0; i < 6; i++) pv[i] = cx.nxt(pv[i]);
                 }
             }
         }
         double D0[SPL] = {}, D1[SPL] = {}, E0[SPL] = {}, E1[SPL] = {}, E2[SPL] = {}, E3[SPL] = {}, Dp[SPL];
+        cx.stamp(6);                    // [local pass D + corrector vector sweep]
         forward(KC0, KC1, D0, D1, E0, E1, E2, E3);
+        cx.stamp(7);                    // [forward sweep 2]
         prev_of(D1, Dp);
         // the gains are dead from here on: their storage takes the multiplier step dl (the slack step ds is recomputed)
         cx.fence();
@@ -632,6 +640,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             if (!cx.any(running && !ok)) break;
             if (!ok) alpha *= 0.7;
         }
+        cx.stamp(8);                    // [local pass E + safeguard]
         // ---- step
         if (running) {
             MPCX_UNROLL
@@ -649,6 +658,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
             it++;
         }
+        cx.stamp(9);                    // [update]
     }
 #undef PX
 #undef WV

@@ -21,6 +21,7 @@ struct HostCx {
     double rcp_fast(double v) const { return 1.0 / v; }
     double rcp_seed(double v) const { return 1.0 / v; }
     void fence() const {}
+    void stamp(int) const {}
     double ld_s(int k) const { return s[k]; }
     double ld_l(int k) const { return l[k]; }
     double ld_k(int j) const { return k[j]; }
