@@ -203,6 +203,12 @@ typedef struct {
 int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *cl,
                              int32_t n_steps, int32_t use_graph);
 
+/* ---- which kernel solves the QP: 0 = automatic (the stage-structured solver), 1 = condensed
+ * (csrc/mpcx_qp.hip, one wavefront per problem, any T <= MPCX_T_MAX), 2 = stage-structured (csrc/mpcx_qp_quad.hip, eight lanes per
+ * problem, any T <= MPCX_T_MAX).  Same problem, same iteration, same exit rules: the choice changes speed, not results
+ * (agreement <= 1e-9 is tested).  The environment variable MPCX_QP_KERNEL=wave|stage sets the default of new contexts. */
+int32_t mpcx_set_qp_solver(mpcx_ctx *ctx, int32_t which);
+
 /* ---- measurement hook: while enabled, every mpcx_qp_solve_batch launch (direct or through mpcx_closed_loop_run
  * without a graph) is bracketed by a pair of HIP events on the context's stream.  mpcx_profile_qp_read waits for
  * the recorded launches, returns their summed duration and count, and clears the record. */

@@ -43,6 +43,7 @@ mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
     c->pred_cap = 0;
     c->loop_exec = nullptr;
     c->prof_qp = false;
+    c->qp_solver = 0;
     c->tune = nullptr;
     c->tune_rows = 0;
     memset(c->loop_key, 0, sizeof c->loop_key);
@@ -78,6 +79,13 @@ int32_t mpcx_set_instance_tuning(mpcx_ctx *ctx, const mpcx_qp_tuning *rows, int3
         return mpcx_fail(ctx, MPCX_E_INVALID, "set_instance_tuning: rows and n_rows must both be given or both be empty");
     ctx->tune = rows;
     ctx->tune_rows = n_rows;
+    return MPCX_OK;
+}
+
+int32_t mpcx_set_qp_solver(mpcx_ctx *ctx, int32_t which) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (which < 0 || which > 2) return mpcx_fail(ctx, MPCX_E_INVALID, "set_qp_solver: 0 (automatic), 1 (condensed) or 2 (stage-structured)");
+    ctx->qp_solver = which;
     return MPCX_OK;
 }
 

@@ -18,6 +18,7 @@ struct mpcx_ctx {
     unsigned char loop_key[640]; // descriptor + parameters the cached graph was captured for
     const mpcx_qp_tuning *tune; // per-instance tuning rows (device) or nullptr
     int32_t tune_rows;
+    int qp_solver;              // 0 = automatic, 1 = condensed (one wavefront per QP), 2 = stage-structured (mpcx_set_qp_solver)
     bool prof_qp;               // bracket qp_kernel launches with events (mpcx_profile_qp)
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs recorded so far
     std::vector<hipEvent_t> prof_free; // recycled events

@@ -40,6 +40,10 @@
 #define STAGE_BARRIER
 #endif
 
+#ifndef MPCX_STAGE_AUTO_T
+#define MPCX_STAGE_AUTO_T MPCX_T_MAX   // horizons up to this use the stage-structured solver unless told otherwise
+#endif
+
 namespace mpcx {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -644,10 +648,12 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         (void)hipEventRecord(e0, ctx->stream);
     }
     const int T = ctx->mpc.T;
-    // T <= 20: stage-structured solver, four lanes per problem (mpcx_qp_quad.hip); longer horizons (and MPCX_QP_KERNEL=wave):
-    // the condensed solver of this file, one wavefront per problem
-    static const bool force_wave = [] { const char *e = getenv("MPCX_QP_KERNEL"); return e && !strcmp(e, "wave"); }();
-    if (T <= 20 && !force_wave) mpcx::launch_qp_stage(a, ctx->stream, ctx->n_cu);
+    // stage-structured solver, eight lanes per problem (mpcx_qp_quad.hip) or the condensed solver of this file, one wavefront
+    // per problem: mpcx_set_qp_solver / MPCX_QP_KERNEL=wave|stage choose; by default horizons <= MPCX_STAGE_AUTO_T take the former
+    static const int env_solver = [] { const char *e = getenv("MPCX_QP_KERNEL"); return !e ? 0 : !strcmp(e, "wave") ? 1 : !strcmp(e, "stage") ? 2 : 0; }();
+    const int solver = ctx->qp_solver ? ctx->qp_solver : env_solver;
+    const bool use_stage = solver == 2 || (solver == 0 && T <= MPCX_STAGE_AUTO_T);
+    if (use_stage) mpcx::launch_qp_stage(a, ctx->stream, ctx->n_cu);
     else if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream, grid);
     else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream, grid);
     else if (T <= 20) mpcx::launch_qp<20>(a, ctx->stream, grid);

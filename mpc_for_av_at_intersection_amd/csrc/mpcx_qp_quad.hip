@@ -126,7 +126,8 @@ void launch_qp_group(const QpArgs &a, hipStream_t st, int n_cu) {
 void launch_qp_stage(const QpArgs &a, hipStream_t st, int n_cu) {
     const int T = a.p.T;
     if (T <= 16) launch_qp_group<8, 2>(a, st, n_cu);
-    else launch_qp_group<8, 3>(a, st, n_cu);
+    else if (T <= 24) launch_qp_group<8, 3>(a, st, n_cu);
+    else launch_qp_group<8, 4>(a, st, n_cu);
 }
 
 }  // namespace mpcx

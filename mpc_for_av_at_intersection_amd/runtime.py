@@ -268,6 +268,10 @@ class Context:
             self._chk(self.lib.mpcx_set_instance_tuning(self._ctx, _ptr(rows), int(rows.shape[0])))
         self._tuning = rows
 
+    def set_qp_solver(self, which: str):
+        """'auto', 'condensed' (one wavefront per QP) or 'stage' (stage-structured solver, eight lanes per QP)"""
+        self._chk(self.lib.mpcx_set_qp_solver(self._ctx, {'auto': 0, 'condensed': 1, 'stage': 2}[which]))
+
     def profile_qp(self, enable: bool):
         """bracket every qp_kernel launch with HIP events on the context's stream (mpcx_profile_qp)"""
         self._chk(self.lib.mpcx_profile_qp(self._ctx, 1 if enable else 0))
