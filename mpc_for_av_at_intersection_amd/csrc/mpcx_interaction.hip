@@ -187,6 +187,11 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
 constexpr int MAXREM = MPCX_MAX_REMAINING;
 constexpr int MAXF = MPCX_EGO_FRAMES_MAX;
 
+#ifdef MPCX_INTER_PROFILE
+#define ISTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd((unsigned long long *)(a.hit_xy + 2 * (size_t)a.P) + (k), t_ - t_last); t_last = t_; } while (0)
+#else
+#define ISTAMP(k) do {} while (0)
+#endif
 __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     __shared__ double s_cum[MAXREM];
     __shared__ int s_keep[MAXF];
@@ -194,6 +199,9 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     __shared__ double s_box[NSEG][4];     // bounding boxes of the ego discs per run of frames
 
     const int p = blockIdx.x, lane = threadIdx.x;
+#ifdef MPCX_INTER_PROFILE
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
     const mpcx_interaction_params &ip = a.ip;
     const double *path = a.path + 3 * (size_t)a.path_off[p];
     const double *pcs = a.path_cs + 2 * (size_t)a.path_off[p];
@@ -233,6 +241,7 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
             }
         }
     }
+    ISTAMP(0);      // distance / step-length pass
     if (advance) {
         if (n_old <= 1) tidx = t_old;
         else if (n_old == 2) tidx = t_old + 1;
@@ -264,6 +273,7 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
         return;
     }
     __syncthreads();
+    ISTAMP(1);      // three-smallest selection
     // ---- mpc_intersection.py:110-116 + trajectories.py:72-86: ego prediction = resample_curve(trajectory, dl_k)
     if (lane == 0) {                      // np.cumsum: strictly sequential adds (one lane; loads batched 16 at a time)
         double c = 0.0;
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
         for (; i < n; i++) { c = __dadd_rn(c, s_cum[shift + i]); s_cum[shift + i] = c; }
     }
     __syncthreads();
+    ISTAMP(2);      // sequential cumsum
     const bool accel_phase = v < ip.max_speed;
     const double dl_const = __dmul_rn(ip.dt, ip.max_speed);
     int base = 0;
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
     }
     (void)overflow;
     __syncthreads();
+    ISTAMP(3);      // resample
     // ego disc centres per kept pose
     for (int f = lane; f < na; f += WAVE) {
         const int i = s_keep[f];
@@ -325,21 +337,27 @@ __global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
         }
     }
     __syncthreads();
+    ISTAMP(4);      // ego discs
     const int ooff = a.obs_off[p], oskip = a.obs_skip ? a.obs_skip[p] : -1;
     double hx, hy;
     const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, lane, hx, hy);
+    ISTAMP(5);      // conflict search (+ path scan on a hit)
     if (first < 0) {
         if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
     }
     // ---- collision_avoidance.py:107-119 on trajectory_full, then mpc_intersection.py:130-134
     int cut = 0x7fffffff;
-    for (int j = lane; j < len; j += WAVE)
-        if (dist2d(path[3 * j], path[3 * j + 1], hx, hy) <= 0.001) cut = j < cut ? j : cut;
+    {
+        const double cr = 0.001, cr2lo = cr * cr * (1.0 - 1e-12), cr2hi = cr * cr * (1.0 + 1e-12);
+        for (int j = lane; j < len; j += WAVE)          // same decision as sqrt(dx*dx + dy*dy) <= 0.001, no sqrt on the bulk
+            if (within(path[3 * j], path[3 * j + 1], hx, hy, cr, cr2lo, cr2hi)) cut = j < cut ? j : cut;
+    }
     cut = wave_min_i(cut);
     int cl = len;
     if (cut != 0x7fffffff) { cl = cut - ip.cutoff_margin; cl = cl > tidx + 1 ? cl : tidx + 1; }
     if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = hx; a.hit_xy[2 * p + 1] = hy; a.cut_len[p] = cl; }
+    ISTAMP(6);      // cut index
 }
 
 // ------------------------------------------------------------------------------------------------------------
