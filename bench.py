@@ -46,7 +46,7 @@ def pmc_traffic_bytes(kernel='qp_'):
         return None
     vals = {}
     for line in open(path):
-        parts = line.strip().split(',')
+        parts = line.strip().rsplit(',', 2)          # kernel names contain commas (template arguments)
         if len(parts) == 3 and kernel in parts[0] and parts[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
             vals[parts[1]] = float(parts[2])
     if len(vals) != 2:
