@@ -59,7 +59,9 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     double Wxx[SPL] = {}, Wxy[SPL] = {}, Wyy[SPL] = {};       // 2*W_{t+1} xy block (mpc.py:157-170)
     bool ended[SPL] = {}, uend[SPL] = {};                     // x_{t+1} / u_t fall on the clipped tail of the reference (Qf / R_end)
     double U0[SPL] = {}, U1[SPL] = {};                        // a_t, delta_t
-    double X0[SPL] = {}, X1[SPL] = {}, X2[SPL] = {}, X3[SPL] = {};    // x_{t+1}
+    // x_{t+1} as tracking error: X0, X1, X3 = (x, y, psi) - reference, X2 = v itself (the speed rows need it), XRV = reference speed.
+    // The reference window is read once per problem; the iterate moves by alpha * dx either way.
+    double X0[SPL] = {}, X1[SPL] = {}, X2[SPL] = {}, X3[SPL] = {}, XRV[SPL] = {};
     bool act[SPL] = {}, rate[SPL] = {};
     double PH[SPL] = {};                                      // yaw of the linearisation point (for C_t)
     double x00 = 0.0, x01 = 0.0, x02 = 0.0, x03 = 0.0;
@@ -162,9 +164,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++) {
             const int t = q * SPL + ls;
-            const int tc = t + 1 <= T ? t + 1 : T;        // slots beyond the horizon read a valid column; their weights are zero
-            const double e0 = X0[ls] - pb.xref[0 * W + tc], e1 = X1[ls] - pb.xref[1 * W + tc];
-            const double e2 = X2[ls] - pb.xref[2 * W + tc], e3 = X3[ls] - pb.xref[3 * W + tc];
+            const double e0 = X0[ls], e1 = X1[ls], e2 = X2[ls] - XRV[ls], e3 = X3[ls];
             G0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; G1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; G2[ls] = WV(ls) * e2; G3[ls] = WP(ls) * e3;
             const bool has_next = act[ls] && (t + 1 < T);
             double g0 = RA_(ls) * U0[ls], g1 = RS_(ls) * U1[ls];
@@ -234,6 +234,13 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         hnorm = fmax(fmax(fmax(1.0, fabs(P.max_accel)), fmax(fabs(P.max_decel), fabs(P.max_steer))),
                                   fmax(fabs(rmax), fmax(fabs(P.max_speed - x02), fabs(x02 - P.min_speed))));
         rollout(false, X0, X1, X2, X3);
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++) {
+            const int t = q * SPL + ls;
+            const int tc = t + 1 <= T ? t + 1 : T;        // slots beyond the horizon read a valid column; their weights are zero
+            X0[ls] -= pb.xref[0 * W + tc]; X1[ls] -= pb.xref[1 * W + tc]; X3[ls] -= pb.xref[3 * W + tc];
+            XRV[ls] = pb.xref[2 * W + tc];
+        }
         prev_of(U1, Dprev);
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++)
