@@ -1,7 +1,9 @@
-// mpcx_qp_quad.hip -- device build of the stage-structured QP solver (mpcx_qp_stage.h): FOUR lanes per problem, 16
-// problems per wavefront.  Lane q of a quad owns stages q*SPL .. q*SPL+SPL-1; the Riccati / costate / rollout sweeps hand
-// their carry to the neighbour lane with quad_perm DPP moves (full rate, no LDS), quad-wide reductions are two DPP steps,
-// slacks / multipliers / reciprocal slacks live in LDS as [row][lane] (conflict-free), everything else in registers.
+// mpcx_qp_quad.hip -- device build of the stage-structured QP solver (mpcx_qp_stage.h): EIGHT lanes per problem, eight
+// problems per wavefront (a four-lane geometry is kept for experiments).  Lane q of a group owns stages q*SPL ..
+// q*SPL+SPL-1; the Riccati / costate / rollout sweeps hand their carry to the neighbour lane with row_shl:1 / row_shr:1 DPP
+// moves (full rate, no LDS), group reductions are three DPP butterflies, slacks / multipliers / the state block of the gains
+// live in LDS as [row][lane] (conflict-free, 36 KB per workgroup at SPL = 3 = four workgroups per CU), everything else in
+// registers.  Wavefronts are persistent: groups draw problems from a global ticket (QueueSrc).
 #include "mpcx_common.h"
 #include "mpcx_qp_stage.h"
 

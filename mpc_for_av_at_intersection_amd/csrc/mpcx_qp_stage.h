@@ -6,7 +6,7 @@
 // time-varying LQ problem and comes out of one backward Riccati sweep (6-state: dx, dy, dv, dpsi and the previous
 // input pair, which carries the input-rate cost and the steering-rate constraint) plus one forward sweep;
 // the two right-hand sides of the predictor-corrector reuse the stored gains.  O(T) work per iteration instead of
-// O(T^3), and a working set small enough that FOUR LANES hold one problem: lane q of a group owns SPL consecutive
+// O(T^3), and a working set small enough that A FEW LANES (eight on the GPU) hold one problem: lane q of a group owns SPL consecutive
 // stages, sweeps run as LQ "turns" (lane q works while the others wait) with the 6x6 cost-to-go handed to the
 // neighbour lane by DPP, and everything that is local to a stage (slacks, multipliers, residuals, step lengths)
 // runs on all lanes at once.  A wavefront therefore carries 64/LQ problems.
