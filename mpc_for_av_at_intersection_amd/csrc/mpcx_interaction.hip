@@ -439,7 +439,7 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
     { int32_t rc = mpcx_ensure_pred(ctx, (size_t)(n_obs_pool > 0 ? n_obs_pool : 1) * ip->pred_steps * 4); if (rc != MPCX_OK) return rc; }
     if (n_obs_pool > 0) {
         mpcx::PredArgs pa{*ip, n_obs_pool, obs6, ctx->pred};
-        hipLaunchKernelGGL(mpcx::predict_kernel, dim3((n_obs_pool + 255) / 256), dim3(256), 0, ctx->stream, pa);
+        hipLaunchKernelGGL(mpcx::predict_kernel, dim3((n_obs_pool + 63) / 64), dim3(64), 0, ctx->stream, pa);
     }
     mpcx::InterArgs ia{*ip, P, state, path_xyyaw, path_cs, path_off, path_len, prev_cut_len, ctx->pred,
                        obs_off, obs_cnt, obs_skip, traj_idx, hit_idx, hit_xy, cut_len};

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void pack_pool_kernel(PackArgs a) {
 static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *c) {
     const int P = c->P;
     mpcx::PackArgs pa{P, c->state, c->applied, c->obs6};
-    hipLaunchKernelGGL(mpcx::pack_pool_kernel, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, pa);
+    hipLaunchKernelGGL(mpcx::pack_pool_kernel, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, pa);
     int32_t rc = mpcx_interaction_batch(ctx, ip, P, c->state, c->path_xyyaw, c->path_cs, c->path_off, c->path_len,
                                         c->cut_len /* previous step's cut; read before it is rewritten */, P, c->obs6,
                                         c->obs_off, c->obs_cnt, c->obs_skip, c->traj_idx, c->hit_idx, c->hit_xy, c->cut_len);

@@ -132,7 +132,7 @@ extern "C" int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double
     mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end};
     hipLaunchKernelGGL(mpcx::ref_window_kernel, dim3(B), dim3(64), 0, ctx->stream, ra);
     mpcx::RollArgs ro{ctx->mpc, B, state, u_warm, xbar};
-    hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, ro);
+    hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, ro);
     return mpcx_check_launch(ctx, "prepare kernels");
 }
 
@@ -146,6 +146,6 @@ extern "C" int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state
     if (ctx->tune && ctx->tune_rows != B)
         return mpcx_fail(ctx, MPCX_E_INVALID, "plant_step_batch: %d tuning rows are set but the batch has %d agents", ctx->tune_rows, B);
     mpcx::PlantArgs pa{ctx->mpc, B, state, u, status, applied, ctx->tune};
-    hipLaunchKernelGGL(mpcx::plant_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, pa);
+    hipLaunchKernelGGL(mpcx::plant_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, pa);
     return mpcx_check_launch(ctx, "plant_kernel");
 }
