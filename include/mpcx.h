@@ -203,6 +203,14 @@ typedef struct {
 int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *cl,
                              int32_t n_steps, int32_t use_graph);
 
+/* ---- scheduling hint for the next mpcx_qp_solve_batch calls: prev_iters[b] = interior-point iterations problem b took in an
+ * earlier solve of a similar problem (the previous MPC step).  Iteration counts are 5 for most problems with a tail to ~17 and
+ * persist from step to step (correlation ~0.5), so the work queue hands out the problems that took >= 8 iterations first and
+ * the launch does not end on a late-drawn hard one (-8 % launch time on the benchmark workload).  Results do not depend on
+ * the order.  DEVICE pointer, read at the start of each solve (it may alias the `iters` output); NULL clears.
+ * mpcx_closed_loop_run applies the hint by itself. */
+int32_t mpcx_qp_set_order_hint(mpcx_ctx *ctx, const int32_t *prev_iters /*B or NULL*/);
+
 /* ---- which kernel solves the QP: 0 = automatic (the stage-structured solver), 1 = condensed
  * (csrc/mpcx_qp.hip, one wavefront per problem, any T <= MPCX_T_MAX), 2 = stage-structured (csrc/mpcx_qp_quad.hip, eight lanes per
  * problem, any T <= MPCX_T_MAX).  Same problem, same iteration, same exit rules: the choice changes speed, not results

@@ -44,6 +44,9 @@ mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
     c->loop_exec = nullptr;
     c->prof_qp = false;
     c->qp_solver = 0;
+    c->order_hint = nullptr;
+    c->order = nullptr;
+    c->order_cap = 0;
     c->tune = nullptr;
     c->tune_rows = 0;
     memset(c->loop_key, 0, sizeof c->loop_key);
@@ -56,6 +59,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     if (ctx->loop_exec) { (void)hipStreamSynchronize(ctx->stream); (void)hipGraphExecDestroy(ctx->loop_exec); }
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
+    if (ctx->order) (void)hipFree(ctx->order);
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     delete ctx;
@@ -79,6 +83,12 @@ int32_t mpcx_set_instance_tuning(mpcx_ctx *ctx, const mpcx_qp_tuning *rows, int3
         return mpcx_fail(ctx, MPCX_E_INVALID, "set_instance_tuning: rows and n_rows must both be given or both be empty");
     ctx->tune = rows;
     ctx->tune_rows = n_rows;
+    return MPCX_OK;
+}
+
+int32_t mpcx_qp_set_order_hint(mpcx_ctx *ctx, const int32_t *prev_iters) {
+    if (!ctx) return MPCX_E_INVALID;
+    ctx->order_hint = prev_iters;
     return MPCX_OK;
 }
 

@@ -18,6 +18,9 @@ struct mpcx_ctx {
     unsigned char loop_key[640]; // descriptor + parameters the cached graph was captured for
     const mpcx_qp_tuning *tune; // per-instance tuning rows (device) or nullptr
     int32_t tune_rows;
+    const int32_t *order_hint;  // iteration counts of a previous solve (device) or nullptr (mpcx_qp_set_order_hint)
+    int32_t *order;             // scratch: work-queue order built from the hint, and its two counters behind it
+    size_t order_cap;
     int qp_solver;              // 0 = automatic, 1 = condensed (one wavefront per QP), 2 = stage-structured (mpcx_set_qp_solver)
     bool prof_qp;               // bracket qp_kernel launches with events (mpcx_profile_qp)
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs recorded so far
@@ -29,6 +32,7 @@ int32_t mpcx_fail(mpcx_ctx *ctx, int32_t code, const char *fmt, ...);
 int32_t mpcx_check_launch(mpcx_ctx *ctx, const char *what);
 int32_t mpcx_ensure_pred(mpcx_ctx *ctx, size_t need_doubles);   // prediction scratch (mpcx_interaction.hip)
 int32_t mpcx_ensure_ticket(mpcx_ctx *ctx);                      // work-queue word (mpcx_qp.hip)
+int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B);             // work-queue order scratch (mpcx_qp.hip)
 
 namespace mpcx {
 
@@ -46,6 +50,8 @@ struct QpArgs {
     int32_t *status, *iters;
     const mpcx_qp_tuning *tune;   // per-problem rows or nullptr
     int has_tune;                 // tune != NULL, tested on the host like has_warm
+    const int32_t *order;         // ticket -> problem index (hard problems first) or nullptr = identity
+    int has_order;
 };
 
 void launch_qp_stage(const QpArgs &a, hipStream_t st, int n_cu);   // mpcx_qp_quad.hip

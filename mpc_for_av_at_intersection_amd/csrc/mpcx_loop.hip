@@ -39,8 +39,12 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
     rc = mpcx_mpc_prepare_batch(ctx, P, c->state, c->u_sol, c->path_xyyaw, c->path_v, c->path_off, c->cut_len, c->dl,
                                 c->target_ind, c->xref, c->reaches_end, c->xbar);
     if (rc != MPCX_OK) return rc;
+    // hard problems first: the previous step's iteration counts (zero-initialised by the caller) order the work queue
+    const int32_t *hint_before = ctx->order_hint;
+    ctx->order_hint = c->iters;
     rc = mpcx_qp_solve_batch(ctx, P, c->state, c->xref, c->xbar, c->reaches_end, c->u_sol, c->x_sol, c->u_sol,
                              c->status, c->iters, c->kkt);
+    ctx->order_hint = hint_before;
     if (rc != MPCX_OK) return rc;
     return mpcx_plant_step_batch(ctx, P, c->state, c->u_sol, c->status, c->applied);
 }
@@ -62,6 +66,8 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     if (rc != MPCX_OK) return rc;
     rc = mpcx_ensure_ticket(ctx);
     if (rc != MPCX_OK) return rc;
+    rc = mpcx_ensure_order(ctx, (size_t)c->P);
+    if (rc != MPCX_OK) return rc;
 
     if (!use_graph) {
         for (int s = 0; s < n_steps; s++) {
@@ -73,7 +79,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
 
     if (!ctx->stream) return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: graph replay needs a non-default stream");
     unsigned char key[sizeof ctx->loop_key];
-    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 2 * sizeof(void *) <= sizeof key,
+    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 3 * sizeof(void *) <= sizeof key,
                   "loop_key too small");
     memset(key, 0, sizeof key);
     size_t o = 0;
@@ -81,7 +87,8 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     memcpy(key + o, ip, sizeof *ip); o += sizeof *ip;
     memcpy(key + o, &ctx->mpc, sizeof ctx->mpc); o += sizeof ctx->mpc;
     memcpy(key + o, &ctx->pred, sizeof ctx->pred); o += sizeof ctx->pred;
-    memcpy(key + o, &ctx->tune, sizeof ctx->tune);
+    memcpy(key + o, &ctx->tune, sizeof ctx->tune); o += sizeof ctx->tune;
+    memcpy(key + o, &ctx->order, sizeof ctx->order);
     if (!ctx->loop_exec || memcmp(key, ctx->loop_key, sizeof key) != 0) {
         if (ctx->loop_exec) {
             (void)hipStreamSynchronize(ctx->stream);

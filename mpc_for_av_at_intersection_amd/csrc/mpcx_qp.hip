@@ -614,6 +614,34 @@ static void launch_qp(const QpArgs &a, hipStream_t st, int grid) {
 
 }  // namespace mpcx
 
+namespace mpcx {
+// work-queue order from the previous solve's iteration counts: problems that took >= HARD_ITERS go to the front, the others fill
+// the queue from the back; one atomic per wavefront and class
+constexpr int HARD_ITERS = 8;
+__global__ __launch_bounds__(64) void qp_order_kernel(int B, const int32_t *hint, int32_t *order, int32_t *cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
+    const bool in = i < B;
+    const bool hard = in && hint[i] >= HARD_ITERS;
+    const unsigned long long mh = __ballot(hard), me = __ballot(in && !hard);
+    int bh = 0, be = 0;
+    if (lane == 0) { bh = atomicAdd(cnt, __popcll(mh)); be = atomicAdd(cnt + 1, __popcll(me)); }
+    bh = __shfl(bh, 0, 64); be = __shfl(be, 0, 64);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (hard) order[bh + __popcll(mh & below)] = i;
+    else if (in) order[B - 1 - (be + __popcll(me & below))] = i;
+}
+}  // namespace mpcx
+
+int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B) {
+    if (B + 2 <= ctx->order_cap) return MPCX_OK;
+    if (ctx->order) (void)hipFree(ctx->order);
+    ctx->order = nullptr; ctx->order_cap = 0;
+    if (hipMalloc((void **)&ctx->order, (B + 2) * sizeof(int32_t)) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "cannot allocate the work-queue order (%zu entries)", B + 2);
+    ctx->order_cap = B + 2;
+    return MPCX_OK;
+}
+
 int32_t mpcx_ensure_ticket(mpcx_ctx *ctx) {
     if (!ctx->ticket && hipMalloc((void **)&ctx->ticket, sizeof(int32_t)) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "cannot allocate the work-queue word");
@@ -636,8 +664,17 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     const int grid = B < ctx->n_cu * 4 ? B : ctx->n_cu * 4;
     if (ctx->tune && ctx->tune_rows != B)
         return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: %d tuning rows are set but the batch has %d problems", ctx->tune_rows, B);
+    const int32_t *order = nullptr;
+    if (ctx->order_hint) {
+        int32_t rc = mpcx_ensure_order(ctx, (size_t)B);
+        if (rc != MPCX_OK) return rc;
+        if (hipMemsetAsync(ctx->order + B, 0, 2 * sizeof(int32_t), ctx->stream) != hipSuccess)
+            return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipMemsetAsync failed");
+        hipLaunchKernelGGL(mpcx::qp_order_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, B, ctx->order_hint, ctx->order, ctx->order + B);
+        order = ctx->order;
+    }
     mpcx::QpArgs a{ctx->mpc, B, ctx->ticket, u_warm != nullptr, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters,
-                   ctx->tune, ctx->tune != nullptr};
+                   ctx->tune, ctx->tune != nullptr, order, order != nullptr};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (ctx->prof_qp && (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone)) {

@@ -89,7 +89,7 @@ struct QueueSrc {
         if (cx.q == 0) t = atomicAdd(a.ticket, 1);
         t = (int)cx.gsum((double)t);                  // the other lanes contribute 0: everybody gets the leader's ticket
         const bool have = t < a.B;
-        const int b = have ? t : 0;
+        const int b = have ? (a.has_order ? a.order[t] : t) : 0;
         pb = at(b);
         if (TUNED) {
             const mpcx_qp_tuning &tu = a.tune[b];

@@ -268,6 +268,13 @@ class Context:
             self._chk(self.lib.mpcx_set_instance_tuning(self._ctx, _ptr(rows), int(rows.shape[0])))
         self._tuning = rows
 
+    def set_qp_order_hint(self, prev_iters: Optional[torch.Tensor]):
+        """mpcx_qp_set_order_hint: int32 device tensor of the previous solve's iteration counts (may be the `iters` output), or None"""
+        if prev_iters is not None:
+            self._want(prev_iters, torch.int32, None, 'prev_iters')
+        self._chk(self.lib.mpcx_qp_set_order_hint(self._ctx, _ptr(prev_iters)))
+        self._order_hint = prev_iters
+
     def set_qp_solver(self, which: str):
         """'auto', 'condensed' (one wavefront per QP) or 'stage' (stage-structured solver, eight lanes per QP)"""
         self._chk(self.lib.mpcx_set_qp_solver(self._ctx, {'auto': 0, 'condensed': 1, 'stage': 2}[which]))
