@@ -1,0 +1,29 @@
+"""What predicts the IPM iteration count of an agent's QP? (dev study)"""
+import sys, os, heapq
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from mpc_for_av_at_intersection_amd.batch import synthetic_batch
+from mpc_for_av_at_intersection_amd.runtime import Context
+ctx = Context(0)
+sim = synthetic_batch(ctx, B=4096, A=8, T=20, seed=1000)
+rec = []
+for k in range(25):
+    sim.step()
+    s = sim.snapshot()
+    rec.append(dict(it=s['iters'].copy(), v=s['state'][:, 2].copy(), cut=(s['cut_len'] < sim.path_len.cpu().numpy()), re=s['reaches_end'].any(axis=1),
+                    hit=s['hit_idx'] >= 0, a0=s['u'][:, 0, 0].copy(), xbv=s['xbar'][:, 2, :].min(axis=1)))
+def makespan(order, dur, ngroups=8192):
+    h = [0] * ngroups; heapq.heapify(h); end = 0
+    for i in order:
+        t = heapq.heappop(h) + dur[i] + 1; end = max(end, t); heapq.heappush(h, t)
+    return end
+for k in (8, 16, 24):
+    cur = rec[k]['it']; prev = rec[k - 1]
+    print('step', k, 'mean iters %.2f' % cur.mean())
+    for name, f in (('prev it>=8', prev['it'] >= 8), ('prev it>=7', prev['it'] >= 7), ('cut', prev['cut']), ('reaches_end', prev['re']), ('v<0.5', prev['v'] < 0.5), ('v<2', prev['v'] < 2),
+                    ('braking a0<-1', prev['a0'] < -1), ('min xbar v < 0.3', prev['xbv'] < 0.3)):
+        print('   %-18s share %.3f  mean iters if true %.2f / false %.2f   P(it>=8 | true) %.2f' % (name, f.mean(), cur[f].mean() if f.any() else 0, cur[~f].mean(), (cur[f] >= 8).mean() if f.any() else 0))
+    for name, key in (('prev', prev['it'].astype(float)), ('prev + 3*(v<2)', prev['it'] + 3.0 * (prev['v'] < 2)), ('prev+2*cut', prev['it'] + 2.0 * prev['cut']),
+                      ('prev + 2*(minxbv<0.3)', prev['it'] + 2.0 * (prev['xbv'] < 0.3)), ('true', cur.astype(float))):
+        print('   LPT by %-22s -> %d rounds' % (name, makespan(np.argsort(-key, kind='stable'), cur)))
+    print('   FIFO -> %d rounds' % makespan(np.arange(len(cur)), cur))
