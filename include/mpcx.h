@@ -203,13 +203,18 @@ typedef struct {
 int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *cl,
                              int32_t n_steps, int32_t use_graph);
 
-/* ---- scheduling hint for the next mpcx_qp_solve_batch calls: prev_iters[b] = interior-point iterations problem b took in an
- * earlier solve of a similar problem (the previous MPC step).  Iteration counts are 5 for most problems with a tail to ~17 and
- * persist from step to step (correlation ~0.5), so the work queue hands out the problems that took >= 8 iterations first and
- * the launch does not end on a late-drawn hard one (-8 % launch time on the benchmark workload).  Results do not depend on
- * the order.  DEVICE pointer, read at the start of each solve (it may alias the `iters` output); NULL clears.
+/* ---- scheduling hint for the next mpcx_qp_solve_batch calls (results never depend on it).  Interior-point iteration counts
+ * are 5 for most problems with a tail to ~17, and one late-drawn hard problem ends the launch alone, so the work queue is
+ * sorted longest-expected-first (counting sort, 64 bins) by
+ *     key[b] = prev_iters[b]  (+ 6 if ref_now[b] != ref_prev[b]),
+ * prev_iters = iterations problem b took in the previous MPC step (correlation with this step ~0.5), ref_now / ref_prev = any
+ * pair of int32 arrays whose inequality marks a discontinuous change of the problem's reference since then -- the closed loop
+ * passes the cut lengths of the current and the previous step (problems whose path cut moved take 8.0 iterations on average,
+ * the others 5.3).  List-scheduling on recorded counts: ideal 28.7 rounds, FIFO 42-44, this order 31-32.  DEVICE pointers,
+ * read at the start of each solve (prev_iters may alias the `iters` output); each may be NULL; all NULL = FIFO.
  * mpcx_closed_loop_run applies the hint by itself. */
-int32_t mpcx_qp_set_order_hint(mpcx_ctx *ctx, const int32_t *prev_iters /*B or NULL*/);
+int32_t mpcx_qp_set_order_hint(mpcx_ctx *ctx, const int32_t *prev_iters /*B or NULL*/, const int32_t *ref_now /*B or NULL*/,
+                               const int32_t *ref_prev /*B or NULL*/);
 
 /* ---- which kernel solves the QP: 0 = automatic (the stage-structured solver), 1 = condensed
  * (csrc/mpcx_qp.hip, one wavefront per problem, any T <= MPCX_T_MAX), 2 = stage-structured (csrc/mpcx_qp_quad.hip, eight lanes per

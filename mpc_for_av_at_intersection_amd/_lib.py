@@ -84,6 +84,6 @@ def load():
     lib.mpcx_profile_qp_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.mpcx_set_instance_tuning.restype = i32; lib.mpcx_set_instance_tuning.argtypes = [vp, vp, i32]
     lib.mpcx_set_qp_solver.restype = i32; lib.mpcx_set_qp_solver.argtypes = [vp, i32]
-    lib.mpcx_qp_set_order_hint.restype = i32; lib.mpcx_qp_set_order_hint.argtypes = [vp, vp]
+    lib.mpcx_qp_set_order_hint.restype = i32; lib.mpcx_qp_set_order_hint.argtypes = [vp, vp, vp, vp]
     _lib = lib
     return lib

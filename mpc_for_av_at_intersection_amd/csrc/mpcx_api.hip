@@ -45,6 +45,9 @@ mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
     c->prof_qp = false;
     c->qp_solver = 0;
     c->order_hint = nullptr;
+    c->order_now = c->order_prev = nullptr;
+    c->prev_cut = nullptr;
+    c->prev_cut_cap = 0;
     c->order = nullptr;
     c->order_cap = 0;
     c->tune = nullptr;
@@ -60,6 +63,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
     if (ctx->order) (void)hipFree(ctx->order);
+    if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     delete ctx;
@@ -86,9 +90,13 @@ int32_t mpcx_set_instance_tuning(mpcx_ctx *ctx, const mpcx_qp_tuning *rows, int3
     return MPCX_OK;
 }
 
-int32_t mpcx_qp_set_order_hint(mpcx_ctx *ctx, const int32_t *prev_iters) {
+int32_t mpcx_qp_set_order_hint(mpcx_ctx *ctx, const int32_t *prev_iters, const int32_t *ref_now, const int32_t *ref_prev) {
     if (!ctx) return MPCX_E_INVALID;
+    if ((ref_now == nullptr) != (ref_prev == nullptr))
+        return mpcx_fail(ctx, MPCX_E_INVALID, "qp_set_order_hint: ref_now and ref_prev come as a pair");
     ctx->order_hint = prev_iters;
+    ctx->order_now = ref_now;
+    ctx->order_prev = ref_prev;
     return MPCX_OK;
 }
 

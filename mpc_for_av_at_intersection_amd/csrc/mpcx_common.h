@@ -19,6 +19,9 @@ struct mpcx_ctx {
     const mpcx_qp_tuning *tune; // per-instance tuning rows (device) or nullptr
     int32_t tune_rows;
     const int32_t *order_hint;  // iteration counts of a previous solve (device) or nullptr (mpcx_qp_set_order_hint)
+    const int32_t *order_now, *order_prev;   // optional pair: entries that differ mark a discontinuous change of the reference
+    int32_t *prev_cut;          // scratch of mpcx_closed_loop_run: cut lengths of the previous step
+    size_t prev_cut_cap;
     int32_t *order;             // scratch: work-queue order built from the hint, and its two counters behind it
     size_t order_cap;
     int qp_solver;              // 0 = automatic, 1 = condensed (one wavefront per QP), 2 = stage-structured (mpcx_set_qp_solver)

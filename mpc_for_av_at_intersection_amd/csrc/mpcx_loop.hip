@@ -30,6 +30,9 @@ __global__ __launch_bounds__(256) void pack_pool_kernel(PackArgs a) {
 
 static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *c) {
     const int P = c->P;
+    // cut lengths of the previous step: the queue of the QP kernel puts the agents whose cut moved at the front
+    if (hipMemcpyAsync(ctx->prev_cut, c->cut_len, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipMemcpyAsync failed");
     mpcx::PackArgs pa{P, c->state, c->applied, c->obs6};
     hipLaunchKernelGGL(mpcx::pack_pool_kernel, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, pa);
     int32_t rc = mpcx_interaction_batch(ctx, ip, P, c->state, c->path_xyyaw, c->path_cs, c->path_off, c->path_len,
@@ -40,11 +43,11 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
                                 c->target_ind, c->xref, c->reaches_end, c->xbar);
     if (rc != MPCX_OK) return rc;
     // hard problems first: the previous step's iteration counts (zero-initialised by the caller) order the work queue
-    const int32_t *hint_before = ctx->order_hint;
-    ctx->order_hint = c->iters;
+    const int32_t *hint_before = ctx->order_hint, *now_before = ctx->order_now, *prev_before = ctx->order_prev;
+    ctx->order_hint = c->iters; ctx->order_now = c->cut_len; ctx->order_prev = ctx->prev_cut;
     rc = mpcx_qp_solve_batch(ctx, P, c->state, c->xref, c->xbar, c->reaches_end, c->u_sol, c->x_sol, c->u_sol,
                              c->status, c->iters, c->kkt);
-    ctx->order_hint = hint_before;
+    ctx->order_hint = hint_before; ctx->order_now = now_before; ctx->order_prev = prev_before;
     if (rc != MPCX_OK) return rc;
     return mpcx_plant_step_batch(ctx, P, c->state, c->u_sol, c->status, c->applied);
 }
@@ -68,6 +71,13 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     if (rc != MPCX_OK) return rc;
     rc = mpcx_ensure_order(ctx, (size_t)c->P);
     if (rc != MPCX_OK) return rc;
+    if ((size_t)c->P > ctx->prev_cut_cap) {
+        if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
+        ctx->prev_cut = nullptr; ctx->prev_cut_cap = 0;
+        if (hipMalloc((void **)&ctx->prev_cut, (size_t)c->P * sizeof(int32_t)) != hipSuccess)
+            return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: cannot allocate %d cut lengths", c->P);
+        ctx->prev_cut_cap = (size_t)c->P;
+    }
 
     if (!use_graph) {
         for (int s = 0; s < n_steps; s++) {
@@ -79,7 +89,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
 
     if (!ctx->stream) return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: graph replay needs a non-default stream");
     unsigned char key[sizeof ctx->loop_key];
-    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 3 * sizeof(void *) <= sizeof key,
+    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 4 * sizeof(void *) <= sizeof key,
                   "loop_key too small");
     memset(key, 0, sizeof key);
     size_t o = 0;
@@ -88,7 +98,8 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     memcpy(key + o, &ctx->mpc, sizeof ctx->mpc); o += sizeof ctx->mpc;
     memcpy(key + o, &ctx->pred, sizeof ctx->pred); o += sizeof ctx->pred;
     memcpy(key + o, &ctx->tune, sizeof ctx->tune); o += sizeof ctx->tune;
-    memcpy(key + o, &ctx->order, sizeof ctx->order);
+    memcpy(key + o, &ctx->order, sizeof ctx->order); o += sizeof ctx->order;
+    memcpy(key + o, &ctx->prev_cut, sizeof ctx->prev_cut);
     if (!ctx->loop_exec || memcmp(key, ctx->loop_key, sizeof key) != 0) {
         if (ctx->loop_exec) {
             (void)hipStreamSynchronize(ctx->stream);

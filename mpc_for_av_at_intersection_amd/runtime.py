@@ -268,12 +268,15 @@ class Context:
             self._chk(self.lib.mpcx_set_instance_tuning(self._ctx, _ptr(rows), int(rows.shape[0])))
         self._tuning = rows
 
-    def set_qp_order_hint(self, prev_iters: Optional[torch.Tensor]):
-        """mpcx_qp_set_order_hint: int32 device tensor of the previous solve's iteration counts (may be the `iters` output), or None"""
-        if prev_iters is not None:
-            self._want(prev_iters, torch.int32, None, 'prev_iters')
-        self._chk(self.lib.mpcx_qp_set_order_hint(self._ctx, _ptr(prev_iters)))
-        self._order_hint = prev_iters
+    def set_qp_order_hint(self, prev_iters: Optional[torch.Tensor], ref_now: Optional[torch.Tensor] = None,
+                          ref_prev: Optional[torch.Tensor] = None):
+        """mpcx_qp_set_order_hint: int32 device tensors -- the previous solve's iteration counts (may be the `iters` output) and,
+        optionally, a pair whose inequality marks problems whose reference jumped (e.g. cut lengths now / before); None clears"""
+        for t in (prev_iters, ref_now, ref_prev):
+            if t is not None:
+                self._want(t, torch.int32, None, 'order hint')
+        self._chk(self.lib.mpcx_qp_set_order_hint(self._ctx, _ptr(prev_iters), _ptr(ref_now), _ptr(ref_prev)))
+        self._order_hint = (prev_iters, ref_now, ref_prev)
 
     def set_qp_solver(self, which: str):
         """'auto', 'condensed' (one wavefront per QP) or 'stage' (stage-structured solver, eight lanes per QP)"""

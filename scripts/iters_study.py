@@ -11,7 +11,7 @@ for k in range(25):
     sim.step()
     s = sim.snapshot()
     rec.append(dict(it=s['iters'].copy(), v=s['state'][:, 2].copy(), cut=(s['cut_len'] < sim.path_len.cpu().numpy()), re=s['reaches_end'].any(axis=1),
-                    hit=s['hit_idx'] >= 0, a0=s['u'][:, 0, 0].copy(), xbv=s['xbar'][:, 2, :].min(axis=1)))
+                    hit=s['hit_idx'] >= 0, cutlen=s['cut_len'].copy(), tind=s['target_ind'].copy(), st=s['status'].copy(), a0=s['u'][:, 0, 0].copy(), xbv=s['xbar'][:, 2, :].min(axis=1)))
 def makespan(order, dur, ngroups=8192):
     h = [0] * ngroups; heapq.heapify(h); end = 0
     for i in order:
@@ -20,10 +20,17 @@ def makespan(order, dur, ngroups=8192):
 for k in (8, 16, 24):
     cur = rec[k]['it']; prev = rec[k - 1]
     print('step', k, 'mean iters %.2f' % cur.mean())
-    for name, f in (('prev it>=8', prev['it'] >= 8), ('prev it>=7', prev['it'] >= 7), ('cut', prev['cut']), ('reaches_end', prev['re']), ('v<0.5', prev['v'] < 0.5), ('v<2', prev['v'] < 2),
+    now = rec[k]
+    for name, f in (('cut changed now', now['cutlen'] != prev['cutlen']), ('hit flag changed now', now['hit'] != prev['hit']), ('now cut', now['cut']), ('now v<0.5', prev['v'] < 0.5),
+                    ('prev>=8 | cut changed', (prev['it'] >= 8) | (now['cutlen'] != prev['cutlen'])), ('prev it>=8', prev['it'] >= 8), ('prev it>=7', prev['it'] >= 7), ('cut', prev['cut']), ('reaches_end', prev['re']), ('v<0.5', prev['v'] < 0.5), ('v<2', prev['v'] < 2),
                     ('braking a0<-1', prev['a0'] < -1), ('min xbar v < 0.3', prev['xbv'] < 0.3)):
         print('   %-18s share %.3f  mean iters if true %.2f / false %.2f   P(it>=8 | true) %.2f' % (name, f.mean(), cur[f].mean() if f.any() else 0, cur[~f].mean(), (cur[f] >= 8).mean() if f.any() else 0))
-    for name, key in (('prev', prev['it'].astype(float)), ('prev + 3*(v<2)', prev['it'] + 3.0 * (prev['v'] < 2)), ('prev+2*cut', prev['it'] + 2.0 * prev['cut']),
+    for name, key in (('prev + 6*cutchanged', prev['it'] + 6.0 * (now['cutlen'] != prev['cutlen'])), ('prev', prev['it'].astype(float)), ('prev + 3*(v<2)', prev['it'] + 3.0 * (prev['v'] < 2)), ('prev+2*cut', prev['it'] + 2.0 * prev['cut']),
                       ('prev + 2*(minxbv<0.3)', prev['it'] + 2.0 * (prev['xbv'] < 0.3)), ('true', cur.astype(float))):
         print('   LPT by %-22s -> %d rounds' % (name, makespan(np.argsort(-key, kind='stable'), cur)))
+    ch = now['cutlen'] != prev['cutlen']
+    cls = 2 * ch.astype(int) + (prev['it'] >= 8)
+    print('   4 classes (changed, prev>=8) -> %d rounds; 2 classes (changed) -> %d; 3 classes (changed | prev>=8 | rest) -> %d' % (
+        makespan(np.argsort(-cls, kind='stable'), cur), makespan(np.argsort(-ch.astype(int), kind='stable'), cur),
+        makespan(np.argsort(-np.where(ch, 2, (prev['it'] >= 8).astype(int)), kind='stable'), cur)))
     print('   FIFO -> %d rounds' % makespan(np.arange(len(cur)), cur))

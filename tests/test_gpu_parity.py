@@ -222,9 +222,10 @@ def test_qp_order_hint_changes_schedule_not_results(ctx):
     ctx.set_qp_order_hint(None)
     ref = {k: v.cpu().numpy() for k, v in ctx.qp_solve(*dev).items()}
     rng = np.random.default_rng(0)
-    for hint in (np.zeros(B), rng.integers(0, 20, B), np.full(B, 50), np.arange(B) % 9):
+    for hint in (np.zeros(B), rng.integers(0, 20, B), np.full(B, 500), np.arange(B) % 9, -np.ones(B)):
         h = ctx.i32(hint)
-        ctx.set_qp_order_hint(h)
+        jump = (ctx.i32(rng.integers(0, 2, B)), ctx.i32(np.zeros(B))) if hint[0] != 0 else (None, None)
+        ctx.set_qp_order_hint(h, *jump)
         out = {k: v.cpu().numpy() for k, v in ctx.qp_solve(*dev).items()}
         for k in ref:
             assert np.array_equal(ref[k], out[k]), k
