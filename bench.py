@@ -183,7 +183,7 @@ def main():
                          'frac': achieved_tf / FP64_PEAK_TFLOPS,
                          'traffic': pmc_traffic_bytes() if (args.horizon == 20 and args.batch == 4096 and args.agents == 8) else None,
                          'traffic_note': 'HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (profiles/r01_pmc_final.csv), same workload; algorithmic bytes per launch = %.3g' % (P * (32 + 2 * 32 * (args.horizon + 1) + (args.horizon + 1) + 16 * args.horizon + 32 * (args.horizon + 1) + 16 * args.horizon + 40)),
-                         'kernel': ('qp_quad_kernel<8,%d> (stage-structured IPM, 8 lanes per QP)' % (2 if args.horizon <= 16 else 3)) if (args.horizon <= 20 and os.environ.get('MPCX_QP_KERNEL') != 'wave') else 'qp_kernel<%d> (condensed IPM, one wavefront per QP)' % args.horizon,
+                         'kernel': ('qp_quad_kernel<8,%d> (stage-structured IPM, 8 lanes per QP)' % (2 if args.horizon <= 16 else 3)) if ((args.horizon > 20 or args.batch * args.agents >= 4096) and os.environ.get('MPCX_QP_KERNEL') != 'wave') else 'qp_kernel<%d> (condensed IPM, one wavefront per QP)' % args.horizon,
                          'kernel_ms': qp_ms, 'kernel_launches_timed': qp_launches, 'flops_per_qp': qp_flops(args.horizon, mean_iters),
                          'note': 'FP64 compute roof (MI355X FP64 matrix rate == FP64 vector rate, 78.6 TFLOP/s); achieved = algorithmic flops of '
                                  'SURVEY 8(d) (condensed, structure-exploiting count) x measured mean IPM iterations / HIP-event kernel time. The '

@@ -216,10 +216,14 @@ int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, c
 int32_t mpcx_qp_set_order_hint(mpcx_ctx *ctx, const int32_t *prev_iters /*B or NULL*/, const int32_t *ref_now /*B or NULL*/,
                                const int32_t *ref_prev /*B or NULL*/);
 
-/* ---- which kernel solves the QP: 0 = automatic (the stage-structured solver), 1 = condensed
- * (csrc/mpcx_qp.hip, one wavefront per problem, any T <= MPCX_T_MAX), 2 = stage-structured (csrc/mpcx_qp_quad.hip, eight lanes per
- * problem, any T <= MPCX_T_MAX).  Same problem, same iteration, same exit rules: the choice changes speed, not results
- * (agreement <= 1e-9 is tested).  The environment variable MPCX_QP_KERNEL=wave|stage sets the default of new contexts. */
+/* ---- which kernel solves the QP:
+ *   0 = automatic: the stage-structured solver for batches of >= 4096 problems or T > 20 (throughput: 8 problems per
+ *       wavefront, O(T) work per iteration), the condensed solver below that (latency: 0.1-0.3 ms per launch against a
+ *       0.4-0.8 ms floor);
+ *   1 = condensed (csrc/mpcx_qp.hip, one wavefront per problem, any T <= MPCX_T_MAX, not competitive beyond T = 20);
+ *   2 = stage-structured (csrc/mpcx_qp_quad.hip, eight lanes per problem, any T <= MPCX_T_MAX).
+ * Same problem, same iteration, same exit rules: the choice changes speed, not results (agreement <= 1e-9 is tested).  The
+ * environment variable MPCX_QP_KERNEL=wave|stage sets the default of new contexts. */
 int32_t mpcx_set_qp_solver(mpcx_ctx *ctx, int32_t which);
 
 /* ---- measurement hook: while enabled, every mpcx_qp_solve_batch launch (direct or through mpcx_closed_loop_run

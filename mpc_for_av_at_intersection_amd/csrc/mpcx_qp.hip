@@ -40,8 +40,12 @@
 #define STAGE_BARRIER
 #endif
 
-#ifndef MPCX_STAGE_AUTO_T
-#define MPCX_STAGE_AUTO_T MPCX_T_MAX   // horizons up to this use the stage-structured solver unless told otherwise
+// automatic choice: the stage-structured solver wins on throughput (8 problems per wavefront, O(T) work) once the batch fills
+// the chip, the condensed solver on latency (one problem per wavefront: 0.08-0.26 ms per launch up to ~1000 problems against a
+// 0.37-0.78 ms floor); measured crossover ~4096 problems for T = 13 / 20, ~6000 for T = 10.  Beyond T = 20 the condensed kernel
+// spills and is never competitive.
+#ifndef MPCX_STAGE_MIN_BATCH
+#define MPCX_STAGE_MIN_BATCH 4096
 #endif
 
 namespace mpcx {
@@ -712,10 +716,10 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     }
     const int T = ctx->mpc.T;
     // stage-structured solver, eight lanes per problem (mpcx_qp_quad.hip) or the condensed solver of this file, one wavefront
-    // per problem: mpcx_set_qp_solver / MPCX_QP_KERNEL=wave|stage choose; by default horizons <= MPCX_STAGE_AUTO_T take the former
+    // per problem: mpcx_set_qp_solver / MPCX_QP_KERNEL=wave|stage choose; by default large batches and long horizons take the former
     static const int env_solver = [] { const char *e = getenv("MPCX_QP_KERNEL"); return !e ? 0 : !strcmp(e, "wave") ? 1 : !strcmp(e, "stage") ? 2 : 0; }();
     const int solver = ctx->qp_solver ? ctx->qp_solver : env_solver;
-    const bool use_stage = solver == 2 || (solver == 0 && T <= MPCX_STAGE_AUTO_T);
+    const bool use_stage = solver == 2 || (solver == 0 && (T > 20 || B >= MPCX_STAGE_MIN_BATCH));
     if (use_stage) mpcx::launch_qp_stage(a, ctx->stream, ctx->n_cu);
     else if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream, grid);
     else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream, grid);

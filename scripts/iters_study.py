@@ -33,4 +33,10 @@ for k in (8, 16, 24):
     print('   4 classes (changed, prev>=8) -> %d rounds; 2 classes (changed) -> %d; 3 classes (changed | prev>=8 | rest) -> %d' % (
         makespan(np.argsort(-cls, kind='stable'), cur), makespan(np.argsort(-ch.astype(int), kind='stable'), cur),
         makespan(np.argsort(-np.where(ch, 2, (prev['it'] >= 8).astype(int)), kind='stable'), cur)))
+    hc = now['hit'] != prev['hit']
+    for bonus in (3, 4, 6, 8, 12):
+        print('   key prev + %d*cut_changed -> %d;  + 3*hit_changed -> %d' % (bonus, makespan(np.argsort(-(prev['it'] + bonus * ch), kind='stable'), cur),
+              makespan(np.argsort(-(prev['it'] + bonus * ch + 3 * hc), kind='stable'), cur)))
+    print('   key min(prev,8) + 6*changed -> %d; key 6*changed + (prev>=8)*3 -> %d' % (makespan(np.argsort(-(np.minimum(prev['it'], 8) + 6 * ch), kind='stable'), cur),
+          makespan(np.argsort(-(6 * ch + 3 * (prev['it'] >= 8)), kind='stable'), cur)))
     print('   FIFO -> %d rounds' % makespan(np.arange(len(cur)), cur))
