@@ -192,10 +192,12 @@ constexpr int MAXF = MPCX_EGO_FRAMES_MAX;
 #else
 #define ISTAMP(k) do {} while (0)
 #endif
-__global__ __launch_bounds__(64) void interaction_kernel(InterArgs a) {
+__global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     __shared__ double s_cum[MAXREM];
     __shared__ int s_keep[MAXF];
-    __shared__ double s_ego[MAXF][4];     // ego disc centres per kept pose: (x0,y0,x1,y1)
+    static_assert(MAXF * 4 <= MAXREM, "the ego discs reuse the cumulative-length table");
+    double (*s_ego)[4] = reinterpret_cast<double (*)[4]>(s_cum);     // ego disc centres per kept pose (x0,y0,x1,y1): written after the
+                                                                     // resampling has consumed s_cum
     __shared__ double s_box[NSEG][4];     // bounding boxes of the ego discs per run of frames
 
     const int p = blockIdx.x, lane = threadIdx.x;
