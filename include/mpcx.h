@@ -102,6 +102,14 @@ int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, int32_t n_n
                           const double *nodes_cs /*n,2: cos,sin of nodes[:,2], or NULL = device sincos*/,
                           double *nbr /*n,P,3*/, double *cost /*n,P*/, uint8_t *collide /*n,P*/);
 
+/* ---- the same expansion for SEVERAL searches in one launch (many independent planners running concurrently): segment s = nodes
+ * seg_off[s] .. seg_off[s+1]-1 of the node table (HOST array, n_seg+1 entries), expanded against models[s] (HOST array of
+ * handles; all with the same number of primitives).  Outputs are laid out exactly as n_seg separate mpcx_expand_batch calls
+ * on the segments would lay them out. */
+int32_t mpcx_expand_multi_batch(mpcx_ctx *ctx, int32_t n_seg, const mpcx_search_model *const *models, const int32_t *seg_off,
+                                const double *nodes /*n,3*/, const double *nodes_cs /*n,2 or NULL*/,
+                                double *nbr /*n,P,3*/, double *cost /*n,P*/, uint8_t *collide /*n,P*/);
+
 /* ---- lib/collision_avoidance.py:66-119 `check_collision_moving_cars` + `get_cutoff_curve_by_position_idx`,
  * lib/moving_obstacles_prediction.py:21-47, trajectories.py:58-86 `resample_curve`, and the caller sequence
  * scenarios/mpc_intersection.py:103-136.  P independent problems (one ego each).  Moving obstacles live in a

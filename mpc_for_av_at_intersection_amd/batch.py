@@ -139,6 +139,7 @@ def stock_routes(ctx: Context, pairs=((1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (3
     from .lib import _session
     from .lib.car_dimensions import BicycleModelDimensions
     from .lib.motion_primitive import load_motion_primitives
+    from .lib.motion_primitive_search import plan_many
     from .lib.motion_primitive_search_modified import MotionPrimitiveSearch
     from .lib.mpc import smooth_yaw
     from .lib.scenario import intersection
@@ -146,9 +147,8 @@ def stock_routes(ctx: Context, pairs=((1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (3
     cd = BicycleModelDimensions()
     mps = load_motion_primitives('bicycle_model')
     routes = []
-    for sp, ti in pairs:
-        search = MotionPrimitiveSearch(intersection(start_pos=sp, turn_indicator=ti), cd, mps, margin=cd.radius, ctx=ctx)
-        _, _, traj = search.run()
+    searches = [MotionPrimitiveSearch(intersection(start_pos=sp, turn_indicator=ti), cd, mps, margin=cd.radius, ctx=ctx) for sp, ti in pairs]
+    for _, _, traj in plan_many(searches):           # all routes planned concurrently (one expansion launch per level)
         traj = np.ascontiguousarray(traj)
         smooth_yaw(traj[:, 2])
         routes.append(traj)

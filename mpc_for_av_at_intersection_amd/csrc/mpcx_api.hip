@@ -44,6 +44,8 @@ mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
     c->loop_exec = nullptr;
     c->prof_qp = false;
     c->qp_solver = 0;
+    c->multi = nullptr;
+    c->multi_cap = 0;
     c->order_hint = nullptr;
     c->order_now = c->order_prev = nullptr;
     c->prev_cut = nullptr;
@@ -63,6 +65,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
     if (ctx->order) (void)hipFree(ctx->order);
+    if (ctx->multi) (void)hipFree(ctx->multi);
     if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);

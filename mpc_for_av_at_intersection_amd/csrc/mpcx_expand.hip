@@ -9,6 +9,7 @@
 // obstacles.py:87-90,140-148), so the per-point early-out acts as an exact bounding-box cull.
 #include "mpcx_common.h"
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 struct mpcx_search_model {
@@ -42,7 +43,7 @@ __device__ __forceinline__ double normalize_angle(double th) {
     return th;
 }
 
-__global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) {
+__device__ __forceinline__ void expand_block(const ExpandArgs &a, unsigned block_in_segment) {
     __shared__ double s_hp[EXP_MAX_ROWS * 3];
     __shared__ double s_xy[EXP_MAX_PTS * 2];
     __shared__ int32_t s_hoff[EXP_MAX_OBST + 1];
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) {
     for (int i = threadIdx.x; i <= a.n_prim; i += blockDim.x) s_toff[i] = a.tmpl_off[i];
     __syncthreads();
 
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long gid = (long long)block_in_segment * blockDim.x + threadIdx.x;
     const long long total = (long long)a.n_nodes * a.n_prim;
     if (gid >= total) return;
     const int node = (int)(gid / a.n_prim), k = (int)(gid % a.n_prim);
@@ -102,6 +103,16 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) {
     o3[2] = normalize_angle(__dadd_rn(lt, th));
     a.cost[gid] = a.edge_cost[k];
     a.collide[gid] = hit ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) { expand_block(a, blockIdx.x); }
+
+// several searches in one launch: segment s = the nodes of one search (its own obstacle / template tables and output ranges);
+// every block belongs to exactly one segment, so the LDS staging of expand_block is unchanged
+__global__ __launch_bounds__(256) void expand_multi_kernel(const ExpandArgs *segs, const int32_t *blk_seg, const int32_t *blk_first) {
+    const int sg = blk_seg[blockIdx.x];
+    const ExpandArgs a = segs[sg];
+    expand_block(a, blockIdx.x - (unsigned)blk_first[sg]);
 }
 
 }  // namespace mpcx
@@ -159,6 +170,50 @@ extern "C" mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_
         return nullptr;
     }
     return m;
+}
+
+extern "C" int32_t mpcx_expand_multi_batch(mpcx_ctx *ctx, int32_t n_seg, const mpcx_search_model *const *models, const int32_t *seg_off,
+                                           const double *nodes, const double *nodes_cs, double *nbr, double *cost, uint8_t *collide) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (n_seg == 0) return MPCX_OK;
+    if (n_seg < 0 || !models || !seg_off) return mpcx_fail(ctx, MPCX_E_INVALID, "expand_multi_batch: null table or negative segment count");
+    const int n_total = seg_off[n_seg];
+    if (n_total == 0) return MPCX_OK;
+    if (n_total < 0 || !nodes || !nbr || !cost || !collide) return mpcx_fail(ctx, MPCX_E_INVALID, "expand_multi_batch: null pointer");
+    const int P = models[0] ? models[0]->n_prim : 0;
+    std::vector<mpcx::ExpandArgs> segs((size_t)n_seg);
+    std::vector<int32_t> blk_seg, blk_first((size_t)n_seg);
+    for (int sg = 0; sg < n_seg; sg++) {
+        const mpcx_search_model *m = models[sg];
+        const int n0 = seg_off[sg], n = seg_off[sg + 1] - n0;
+        if (!m || n < 0 || m->n_prim != P)
+            return mpcx_fail(ctx, MPCX_E_INVALID, "expand_multi_batch: segment %d has no model, a negative size or another primitive count", sg);
+        segs[sg] = mpcx::ExpandArgs{m->n_prim, m->n_obst, m->n_pts, m->n_rows, n, m->d_tmpl_off, m->d_hp_off, m->d_tmpl_xy, m->d_last_pose,
+                                    m->d_edge_cost, m->d_hp, m->d_aabb, nodes + 3 * (size_t)n0, nodes_cs ? nodes_cs + 2 * (size_t)n0 : nullptr,
+                                    nbr + 3 * (size_t)n0 * P, cost + (size_t)n0 * P, collide + (size_t)n0 * P};
+        blk_first[sg] = (int32_t)blk_seg.size();
+        const long long nb = ((long long)n * P + 255) / 256;
+        blk_seg.insert(blk_seg.end(), (size_t)nb, sg);
+    }
+    if (blk_seg.empty()) return MPCX_OK;
+    // one upload: [segment descriptors | block -> segment | first block of each segment]
+    const size_t b0 = segs.size() * sizeof(mpcx::ExpandArgs), b1 = blk_seg.size() * sizeof(int32_t), b2 = blk_first.size() * sizeof(int32_t);
+    const size_t need = b0 + b1 + b2;
+    if (need > ctx->multi_cap) {
+        if (ctx->multi) (void)hipFree(ctx->multi);
+        ctx->multi = nullptr; ctx->multi_cap = 0;
+        if (hipMalloc((void **)&ctx->multi, need * 2) != hipSuccess) return mpcx_fail(ctx, MPCX_E_LAUNCH, "expand_multi_batch: cannot allocate %zu bytes", need * 2);
+        ctx->multi_cap = need * 2;
+    }
+    std::vector<unsigned char> host(need);
+    memcpy(host.data(), segs.data(), b0); memcpy(host.data() + b0, blk_seg.data(), b1); memcpy(host.data() + b0 + b1, blk_first.data(), b2);
+    if (hipMemcpyAsync(ctx->multi, host.data(), need, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)      // `host` goes out of scope: the staging copy must have left it
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "expand_multi_batch: descriptor upload failed");
+    const unsigned char *d = (const unsigned char *)ctx->multi;
+    hipLaunchKernelGGL(mpcx::expand_multi_kernel, dim3((unsigned)blk_seg.size()), dim3(256), 0, ctx->stream,
+                       (const mpcx::ExpandArgs *)d, (const int32_t *)(d + b0), (const int32_t *)(d + b0 + b1));
+    return mpcx_check_launch(ctx, "expand_multi_kernel");
 }
 
 extern "C" void mpcx_search_model_destroy(mpcx_search_model *m) {

@@ -46,6 +46,18 @@ class AStar(Generic[TNode]):
 
     def run(self, start: TNode, is_goal_function: Callable[[TNode], bool],
             heuristic_function: Callable[[TNode], float], debug=False) -> Tuple[float, List[TNode]]:
+        gen = self.run_gen(start, is_goal_function, heuristic_function, debug=debug)
+        try:
+            while True:
+                next(gen)              # no ready_function: never yields
+        except StopIteration as done:
+            return done.value
+
+    def run_gen(self, start: TNode, is_goal_function: Callable[[TNode], bool], heuristic_function: Callable[[TNode], float],
+                debug=False, ready_function: Callable[[TNode], bool] = None):
+        """The same search as a generator: before a node is expanded it is yielded if `ready_function(node)` is false, so a driver
+        can run many searches in lock-step and expand the nodes they wait for in one batch.  Returns (g, path) as the
+        generator's value.  Pop order, tie-breaking and the debug log are those of `run` (this IS `run`)."""
         self._open = [(0, 0, start, start)]
         self._closed = {}
         if debug:
@@ -66,6 +78,8 @@ class AStar(Generic[TNode]):
                     node, parent = parent, closed[parent][1]
                 chain.reverse()
                 return g, chain
+            if ready_function is not None and not ready_function(node):
+                yield node
             for edge_cost, nb in self.neighbor_function(node):
                 nb_g = g + edge_cost
                 known = closed.get(nb)

@@ -81,6 +81,11 @@ class MotionPrimitiveSearch:
                                       heuristic_function=self.distance_to_goal, debug=debug)
         return cost, path, self.path_to_full_trajectory(path)
 
+    def run_gen(self, debug=False):
+        """`run` as a generator for plan_many: yields every node whose expansion is not cached yet; value = (cost, path)"""
+        return self._a_star.run_gen(self._start, is_goal_function=self.is_goal, heuristic_function=self.distance_to_goal, debug=debug,
+                                    ready_function=lambda node: node in self._cache)
+
     @property
     def debug_data(self):
         return self._a_star.debug_data
@@ -131,19 +136,27 @@ class MotionPrimitiveSearch:
                 + self._wh_obstacle * obst + self._wh_center * centre)
 
     # ------------------------------------------------------------------ device expansion
-    def _expand(self, nodes: List[NodeType]):
-        """expand uncached nodes on the GPU; returns the free children that became known"""
-        nodes = [n for n in dict.fromkeys(nodes) if n not in self._cache]
-        if not nodes:
-            return []
+    def _uncached(self, nodes: List[NodeType]) -> List[NodeType]:
+        return [n for n in dict.fromkeys(nodes) if n not in self._cache]
+
+    @staticmethod
+    def _node_arrays(nodes: List[NodeType]):
         arr = np.array(nodes, dtype=np.float64).reshape(-1, 3)
         # cos/sin from the host's numpy -- the library the reference's create_2d_transform_mtx calls -- so successor
         # coordinates (hence exact-equality node identity and exact-tie pop order) are bit-identical to the reference
-        cs = np.column_stack([np.cos(arr[:, 2]), np.sin(arr[:, 2])])
+        return arr, np.column_stack([np.cos(arr[:, 2]), np.sin(arr[:, 2])])
+
+    def _expand(self, nodes: List[NodeType]):
+        """expand uncached nodes on the GPU; returns the free children that became known"""
+        nodes = self._uncached(nodes)
+        if not nodes:
+            return []
+        arr, cs = self._node_arrays(nodes)
         out = self._ctx.expand(self._model, self._ctx.f64(arr), nodes_cs=self._ctx.f64(cs))
         self.kernel_launches += 1
-        nbr = out['nbr'].cpu().numpy()
-        col = out['collide'].cpu().numpy()
+        return self._store(nodes, out['nbr'].cpu().numpy(), out['collide'].cpu().numpy())
+
+    def _store(self, nodes: List[NodeType], nbr: np.ndarray, col: np.ndarray) -> List[NodeType]:
         children = []
         for n, nb, cl in zip(nodes, nbr, col):
             free = [(k, (float(nb[k, 0]), float(nb[k, 1]), float(nb[k, 2]))) for k in range(len(self._names)) if not cl[k]]
@@ -213,3 +226,52 @@ class MotionPrimitiveSearch:
         out = self._ctx.transform(nodes, self._ctx.i32(np.array([offs[nme] for nme in names])), self._ctx.i32(cnts), pts,
                                   int(cnts.max())).cpu().numpy()
         return np.concatenate([out[i, :cnts[i] - 1] for i in range(len(names))], axis=0)
+
+
+def plan_many(searches: List[MotionPrimitiveSearch], debug=False):
+    """Run several independent searches concurrently: every search keeps its own exact queue, heuristic and
+    expansion cache on the host -- pop order, costs and paths are those of `search.run()` -- while the nodes all of them are
+    waiting for (each popped node + its best open nodes, then all their free children) are expanded by ONE
+    mpcx_expand_multi_batch launch per level, whatever the number of searches.  Returns [(cost, path, trajectory), ...]."""
+    if not searches:
+        return []
+    ctx = searches[0]._ctx
+    gens = [s.run_gen(debug=debug) for s in searches]
+    results = [None] * len(searches)
+    waiting = {}
+
+    def advance(i):
+        try:
+            waiting[i] = next(gens[i])
+        except StopIteration as done:
+            waiting.pop(i, None)
+            results[i] = done.value
+
+    def expand_level(requests):
+        """requests: {search index: [nodes]} -> {search index: children}; one launch"""
+        idx = [i for i, nodes in requests.items() if nodes]
+        if not idx:
+            return {}
+        off = np.cumsum([0] + [len(requests[i]) for i in idx])
+        flat = [n for i in idx for n in requests[i]]
+        arr, cs = MotionPrimitiveSearch._node_arrays(flat)
+        out = ctx.expand_multi([searches[i]._model for i in idx], off, ctx.f64(arr), nodes_cs=ctx.f64(cs))
+        nbr, col = out['nbr'].cpu().numpy(), out['collide'].cpu().numpy()
+        kids = {}
+        for j, i in enumerate(idx):
+            searches[i].kernel_launches += 1
+            kids[i] = searches[i]._store(requests[i], nbr[off[j]:off[j + 1]], col[off[j]:off[j + 1]])
+        return kids
+
+    for i in range(len(searches)):
+        advance(i)
+    while waiting:
+        level1 = {i: searches[i]._uncached([node] + searches[i]._a_star.peek_open(searches[i].PREFETCH)) for i, node in waiting.items()}
+        kids = expand_level(level1)
+        expand_level({i: searches[i]._uncached(c) for i, c in kids.items()})        # one level of look-ahead
+        for i in list(waiting):
+            advance(i)
+    out = []
+    for s, (cost, path) in zip(searches, results):
+        out.append((cost, path, s.path_to_full_trajectory(path)))
+    return out

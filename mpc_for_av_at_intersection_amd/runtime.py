@@ -198,6 +198,23 @@ class Context:
                                              _ptr(out['collide'])))
         return out
 
+    def expand_multi(self, models, seg_off, nodes, nodes_cs=None):
+        """mpcx_expand_multi_batch: nodes (n,3) grouped by search, seg_off = n_seg+1 offsets (host ints), models = one
+        SearchModel per segment.  Returns dict(nbr (n,P,3), cost (n,P), collide (n,P)) laid out like separate expand() calls."""
+        n = nodes.shape[0]
+        self._want(nodes, torch.float64, (n, 3), 'nodes')
+        if nodes_cs is not None:
+            self._want(nodes_cs, torch.float64, (n, 2), 'nodes_cs')
+        Pn = models[0].n_prim
+        out = dict(nbr=torch.empty((n, Pn, 3), dtype=torch.float64, device=self.device),
+                   cost=torch.empty((n, Pn), dtype=torch.float64, device=self.device),
+                   collide=torch.empty((n, Pn), dtype=torch.uint8, device=self.device))
+        handles = (C.c_void_p * len(models))(*[m._h for m in models])
+        offs = (C.c_int32 * (len(models) + 1))(*[int(v) for v in seg_off])
+        self._chk(self.lib.mpcx_expand_multi_batch(self._ctx, len(models), handles, offs, _ptr(nodes), _ptr(nodes_cs), _ptr(out['nbr']),
+                                                   _ptr(out['cost']), _ptr(out['collide'])))
+        return out
+
     def interaction(self, ip: InteractionParams, state, path, path_cs, path_off, path_len, prev_cut_len,
                     obs6, obs_off, obs_cnt, obs_skip, traj_idx, out=None):
         """mpcx_interaction_batch. traj_idx updated in place. Returns dict(hit_idx, hit_xy, cut_len)."""
