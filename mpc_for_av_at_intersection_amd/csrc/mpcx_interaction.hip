@@ -352,7 +352,9 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     int cut = 0x7fffffff;
     {
         const double cr = 0.001, cr2lo = cr * cr * (1.0 - 1e-12), cr2hi = cr * cr * (1.0 + 1e-12);
-        for (int j = lane; j < len; j += WAVE)          // same decision as sqrt(dx*dx + dy*dy) <= 0.001, no sqrt on the bulk
+        // (hx, hy) IS path point tidx + first, so the first index within 1 mm cannot lie beyond it: scan [0, tidx + first]
+        const int jend = tidx + first + 1 < len ? tidx + first + 1 : len;
+        for (int j = lane; j < jend; j += WAVE)         // same decision as sqrt(dx*dx + dy*dy) <= 0.001, no sqrt on the bulk
             if (within(path[3 * j], path[3 * j + 1], hx, hy, cr, cr2lo, cr2hi)) cut = j < cut ? j : cut;
     }
     cut = wave_min_i(cut);
