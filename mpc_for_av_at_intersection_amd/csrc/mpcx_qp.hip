@@ -690,8 +690,12 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     const int grid = B < ctx->n_cu * 4 ? B : ctx->n_cu * 4;
     if (ctx->tune && ctx->tune_rows != B)
         return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: %d tuning rows are set but the batch has %d problems", ctx->tune_rows, B);
+    const int T = ctx->mpc.T;
+    static const int env_solver = [] { const char *e = getenv("MPCX_QP_KERNEL"); return !e ? 0 : !strcmp(e, "wave") ? 1 : !strcmp(e, "stage") ? 2 : 0; }();
+    const int solver = ctx->qp_solver ? ctx->qp_solver : env_solver;
+    const bool use_stage = solver == 2 || (solver == 0 && (T > 20 || B >= MPCX_STAGE_MIN_BATCH));
     const int32_t *order = nullptr;
-    if (ctx->order_hint || ctx->order_now) {
+    if (use_stage && (ctx->order_hint || ctx->order_now)) {      // only the stage solver draws from a queue that can be ordered
         int32_t rc = mpcx_ensure_order(ctx, (size_t)B);
         if (rc != MPCX_OK) return rc;
         int32_t *hist = ctx->order + B, *cursor = hist + mpcx::ORDER_BINS;
@@ -714,12 +718,8 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         }
         (void)hipEventRecord(e0, ctx->stream);
     }
-    const int T = ctx->mpc.T;
     // stage-structured solver, eight lanes per problem (mpcx_qp_quad.hip) or the condensed solver of this file, one wavefront
     // per problem: mpcx_set_qp_solver / MPCX_QP_KERNEL=wave|stage choose; by default large batches and long horizons take the former
-    static const int env_solver = [] { const char *e = getenv("MPCX_QP_KERNEL"); return !e ? 0 : !strcmp(e, "wave") ? 1 : !strcmp(e, "stage") ? 2 : 0; }();
-    const int solver = ctx->qp_solver ? ctx->qp_solver : env_solver;
-    const bool use_stage = solver == 2 || (solver == 0 && (T > 20 || B >= MPCX_STAGE_MIN_BATCH));
     if (use_stage) mpcx::launch_qp_stage(a, ctx->stream, ctx->n_cu);
     else if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream, grid);
     else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream, grid);
