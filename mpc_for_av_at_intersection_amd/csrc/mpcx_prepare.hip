@@ -22,8 +22,8 @@ struct RefArgs {
     uint8_t *re;
 };
 
-__global__ __launch_bounds__(64) void ref_window_kernel(RefArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void ref_window_block(const RefArgs &a, int b) {
+    const int lane = threadIdx.x;
     const int T = a.p.T, W = T + 1;
     const double *path = a.path + 3 * (size_t)a.path_off[b];
     const double *pv = a.path_v ? a.path_v + (size_t)a.path_off[b] : nullptr;   // mpc_with_speed.py:103-104
@@ -75,8 +75,7 @@ struct RollArgs {
     double *xbar;
 };
 
-__global__ __launch_bounds__(256) void rollout_kernel(RollArgs a) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void rollout_thread(const RollArgs &a, int b) {
     if (b >= a.B) return;
     const int T = a.p.T, W = T + 1;
     double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2], th = a.state[4 * b + 3];
@@ -88,6 +87,16 @@ __global__ __launch_bounds__(256) void rollout_kernel(RollArgs a) {
         plant_step(a.p, x, y, v, th, ai, di);
         xb[t] = x; xb[W + t] = y; xb[2 * W + t] = v; xb[3 * W + t] = th;
     }
+}
+
+// One launch for both halves of mpc.py:211-239's preparation: the first ceil(B/64) blocks roll the warm start out (one thread per
+// instance), the following B blocks select the reference window (one wavefront per instance).  The two are independent, and
+// the rollout is a chain of T dependent sincos/tan evaluations per thread, so running it BESIDE the window selection instead of
+// after it hides it completely.
+__global__ __launch_bounds__(64) void prepare_kernel(RefArgs ra, RollArgs ro) {
+    const int nroll = (ro.B + 63) / 64;          // the long-running rollout blocks are dispatched first
+    if ((int)blockIdx.x < nroll) rollout_thread(ro, (int)blockIdx.x * 64 + threadIdx.x);
+    else ref_window_block(ra, (int)blockIdx.x - nroll);
 }
 
 struct PlantArgs {
@@ -130,9 +139,8 @@ extern "C" int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double
         return mpcx_fail(ctx, MPCX_E_INVALID, "mpc_prepare_batch: null pointer, negative batch or dl <= 0");
     if (B == 0) return MPCX_OK;
     mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end};
-    hipLaunchKernelGGL(mpcx::ref_window_kernel, dim3(B), dim3(64), 0, ctx->stream, ra);
     mpcx::RollArgs ro{ctx->mpc, B, state, u_warm, xbar};
-    hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, ro);
+    hipLaunchKernelGGL(mpcx::prepare_kernel, dim3(B + (B + 63) / 64), dim3(64), 0, ctx->stream, ra, ro);
     return mpcx_check_launch(ctx, "prepare kernels");
 }
 
