@@ -167,18 +167,24 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
     const double ox = pred[((size_t)pool * steps + g) * 4 + 2 * co], oy = pred[((size_t)pool * steps + g) * 4 + 2 * co + 1];
 
     // ---- collision_avoidance.py:88-104: earliest pose of the detailed path (front-disc block, then rear-disc block)
+    // The answer is the smallest index of the front-disc block if that block has a hit at all, else the smallest of the
+    // rear-disc block: each block is walked in index order, 64 poses at a time, and left at the first batch with a hit.
     int first = 0x7fffffff;
-    for (int i = lane; i < n; i += WAVE) {
-        const double px = rem[3 * i], py = rem[3 * i + 1], c = rcs[2 * i], s = rcs[2 * i + 1];
-#pragma unroll
-        for (int d = 0; d < 2; d++) {
-            const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
-            const double ex = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
-            const double ey = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
-            if (within(ox, oy, ex, ey, md, md2lo, md2hi)) { const int key = d * n + i; first = key < first ? key : first; }
+    for (int d = 0; d < 2 && first == 0x7fffffff; d++) {
+        const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
+        for (int i0 = 0; i0 < n; i0 += WAVE) {
+            const int i = i0 + lane;
+            bool hit = false;
+            if (i < n) {
+                const double px = rem[3 * i], py = rem[3 * i + 1], c = rcs[2 * i], s = rcs[2 * i + 1];
+                const double ex = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
+                const double ey = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
+                hit = within(ox, oy, ex, ey, md, md2lo, md2hi);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) { first = d * n + i0 + (int)__ffsll((long long)m) - 1; break; }      // wave-uniform
         }
     }
-    first = wave_min_i(first);
     first = (first == 0x7fffffff) ? 0 : first % n;      // argmax of an all-False mask is 0
     hx = rem[3 * first]; hy = rem[3 * first + 1];
     return first;
