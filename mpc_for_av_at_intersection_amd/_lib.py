@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmpcx.so')
+# MPCX_LIB: developer override (instrumented builds of the same sources, scripts/*_phase_profile.py); the product is libmpcx.so
+LIB_PATH = os.environ.get('MPCX_LIB') or os.path.join(_HERE, 'libmpcx.so')
 _lib = None
 
 c_dp = C.c_void_p  # device pointers travel as raw addresses
