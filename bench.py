@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of BASELINE.json: MPC timesteps/s, N=20 horizon, 8-agent intersection.
+"""bench.py -- headline benchmark of BASELINE.json: MPC timesteps/s, N=20 horizon, 8-agent intersection, batch=4096.
 
-One "step" = one pass of the hot path over one batch: every (instance, agent) pair of `--batch` instances x 8 agents
-goes through the body of the reference's scenario loop (conflict search + path cut, reference window, rollout, QP,
-plant) -- see mpc_for_av_at_intersection_amd/batch.py.  One *timestep* of the metric = one INSTANCE (all 8 agents)
-advanced by DT = 0.2 s.  Weak scaling: every rank owns `--batch` instances (independent => no data-path
-collective); value = N * batch * steps / max-over-ranks time.
+One "step" = one pass of the hot path over the batch: every (instance, agent) pair goes through the body of the reference's
+scenario loop (conflict search + path cut, reference window, rollout, QP, plant) -- mpc_for_av_at_intersection_amd/batch.py.
+One *timestep* of the metric = one INSTANCE (all 8 agents) advanced by DT = 0.2 s.
+
+The workload is ONE batch of `--batch` (4096) instances whatever --gpus is: rank r owns instances
+shard_instances(4096, r, N) -- strong scaling, no data-path collective (all agents of an instance are rank-local).
+value = 4096 * steps / max-over-ranks time.  Extra keys of the same JSON line (each measured after the headline region):
+  steady_state   the same measurement after >= 100 closed-loop steps (traffic has built up; different iteration mix)
+  expand         motion-primitive expansion of a 2^20-node Prius frontier, HIP-event timed
+  agent_sharded  (N > 1) the layout with a real exchange step: agents sharded over ranks, one RCCL all-gather per step
+  weak           (N > 1) every rank runs the full 4096-instance batch
+  cpu_baseline   the oracle on this host: one thread, and all cores (threads over agents in C)
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -24,12 +32,22 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix rate (datasheet; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md chip table
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_final.csv')
 
 
-def qp_flops(T: int, iters: float) -> float:
-    """algorithmic (structure-exploiting) FP64 flops of one agent-QP."""
+def qp_flops_condensed(T: int, iters: float) -> float:
+    """algorithmic (structure-exploiting, condensed) FP64 flops of one agent-QP."""
     n, m = 2 * T, 8 * T
     return (16.0 / 3.0) * T ** 3 + 16.0 * T ** 2 + iters * (n ** 3 / 3.0 + 4.0 * n ** 2 + 6.0 * T ** 2 + 12.0 * m)
+
+
+def qp_flops_stage(T: int, iters: float) -> float:
+    """FP64 flops the stage-structured solver (csrc/mpcx_qp_stage.h) needs per agent-QP, counted on its source, FMA = 2:
+    per iteration and stage: Riccati step 150 FMA + 2x2 elimination 12, costate 13, two forward sweeps 2 x 22, corrector
+    vector sweep 40, row passes 8 rows x ~36 flops; set-up per stage: two sincos (~2 x 40), weights 12, two rollouts 2 x 12."""
+    per_iter = 2 * (150 + 12 + 13 + 2 * 22 + 40) + 8 * 36
+    setup = 2 * 40 + 12 + 2 * 12
+    return T * (setup + iters * per_iter)
 
 
 def agent_step_bytes(T: int, A: int) -> float:
@@ -37,15 +55,18 @@ def agent_step_bytes(T: int, A: int) -> float:
     return 32 + 16 * T + 48 * (A - 1) + 24 * (T + 1) + 32 * (T + 1) + 16 * T + 8
 
 
+def qp_launch_bytes(T: int, P: int) -> float:
+    """algorithmic HBM bytes of one QP launch: x0, xref, xbar, reaches_end, warm start in; x, u, status/iters/kkt out"""
+    return P * (32 + 2 * 32 * (T + 1) + (T + 1) + 16 * T + 32 * (T + 1) + 16 * T + 40)
+
+
 def pmc_traffic_bytes(kernel='qp_'):
-    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/r01_pmc_final.csv;
-    bench.py cannot run the profiler on itself): 2 x FETCH_SIZE (gfx950 under-reports reads by 2x, MI355X_MICROARCH.md
-    'HBM') + WRITE_SIZE, KiB -> bytes. None when the file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_final.csv')
-    if not os.path.exists(path):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (bench.py cannot run the profiler on
+    itself): 2 x FETCH_SIZE (gfx950 under-reports reads by 2x, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE, KiB -> bytes."""
+    if not os.path.exists(PMC_FILE):
         return None
     vals = {}
-    for line in open(path):
+    for line in open(PMC_FILE):
         parts = line.strip().rsplit(',', 2)          # kernel names contain commas (template arguments)
         if len(parts) == 3 and kernel in parts[0] and parts[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
             vals[parts[1]] = float(parts[2])
@@ -54,31 +75,60 @@ def pmc_traffic_bytes(kernel='qp_'):
     return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
 
 
-def cpu_baseline(sim, snap_before, n_agents: int):
-    """Oracle (CPU port of the same per-agent step, oracle/) timed on this host, single thread, on a bounded sample
-    of the SAME workload: the first `n_agents` (instance, agent) pairs of rank 0's batch, from the captured state."""
+def host_cores():
+    """(threads this process may really use, CPU model string)"""
+    n = len(os.sched_getaffinity(0))
+    try:                                            # cgroup v2 CPU quota of the box
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(math.ceil(float(quota) / float(period)))))
+    except Exception:
+        pass
+    model = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return n, model
+
+
+def cpu_baseline(sim, snap, n_agents: int):
+    """Oracle (CPU port of the same per-agent step, oracle/) timed on this host on a bounded sample of the SAME workload: the
+    first n (instance, agent) pairs of rank 0's batch from the captured state -- once on one thread, once on all cores, both
+    through orc_agent_steps_mt (C, pthreads over agents; no Python per agent-step)."""
     from oracle import oracle_py as orc
+    A = sim.A
     po = orc.MpcParams(T=sim.params.T, L=sim.params.L)
     tab = sim.path.cpu().numpy(); off = sim.path_off.cpu().numpy(); ln = sim.path_len.cpu().numpy()
     centers = np.asarray(sim.ip.circle_centers).reshape(2, 2)
-    A = sim.A
-    t0 = time.perf_counter()
-    done = 0
-    for p in range(n_agents):
-        b = p // A
-        others = [q for q in range(b * A, (b + 1) * A) if q != p]
-        st = snap_before['state']; ap = snap_before['applied']
-        obs6 = np.column_stack([st[others][:, [0, 1, 2, 3]], ap[others][:, 1], ap[others][:, 0]])
-        orc.agent_step(po, tab[off[p]:off[p] + ln[p]], sim.dl, st[p], obs6, int(snap_before['traj_idx'][p]),
-                       int(snap_before['prev_cut'][p]), int(snap_before['target_ind'][p]), snap_before['u'][p],
-                       centers, sim.ip.radius, sim.ip.cutoff_margin)
-        done += 1
-        if time.perf_counter() - t0 > 25.0:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=(done / A) / dt, unit='MPC timesteps/s', cores=1, kind='port',
-                sample='%d agent-steps (= %.1f instance timesteps) of rank 0 batch, state after warm-up, oracle/liboracle.so single thread, %.1f s'
-                       % (done, done / A, dt), agent_qp_per_s=done / dt)
+    cores, model = host_cores()
+
+    P = len(snap['state'])
+
+    def run(n, threads, seconds):
+        """passes over the first n agents until `seconds` have gone by; returns (agent-steps done, seconds, threads that ran)"""
+        n = max(A, (min(n, P) // A) * A)
+        done, ran, t0 = 0, threads, time.perf_counter()
+        while True:
+            r = orc.agent_steps_batch(po, threads, A, tab, off[:n], ln[:n], sim.dl, snap['state'][:n], snap['applied'][:n], snap['u'][:n],
+                                      snap['traj_idx'][:n], snap['prev_cut'][:n], snap['target_ind'][:n], centers, sim.ip.radius,
+                                      sim.ip.cutoff_margin)
+            done += n; ran = r['threads']
+            if time.perf_counter() - t0 >= seconds:
+                return done, time.perf_counter() - t0, ran
+
+    n1, t1, _ = run(min(n_agents, 4096), 1, 0.0)                 # one short pass: calibrates the sample size
+    n1, t1, _ = run(min(n_agents, int(n1 / t1 * 2.5)), 1, 10.0)  # ~10 s on one thread, passes of ~2.5 s
+    nm, tm, ran = run(min(n_agents, P), cores, 10.0)             # ~10 s on all cores, passes over the whole captured batch
+    return dict(value=(nm / A) / tm, unit='MPC timesteps/s', cores=ran, kind='port', cpu_model=model,
+                sample='%d agent-steps (= %d instance timesteps; passes over the %d captured agents of rank 0, state after warm-up), '
+                       'oracle/liboracle.so orc_agent_steps_mt (C, %d pthreads over agents, gcc -O3), %.1f s' % (nm, nm // A, min(n_agents, P), ran, tm),
+                agent_qp_per_s=nm / tm,
+                value_1thread=(n1 / A) / t1, agent_qp_per_s_1thread=n1 / t1,
+                sample_1thread='%d agent-steps on one thread, %.1f s' % (n1, t1))
 
 
 def main():
@@ -86,11 +136,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=4096, help='scenario instances per GPU')
+    ap.add_argument('--batch', type=int, default=4096, help='scenario instances of the WHOLE job (sharded over the GPUs)')
     ap.add_argument('--agents', type=int, default=8)
     ap.add_argument('--horizon', type=int, default=20)
-    ap.add_argument('--cpu-agents', type=int, default=32768, help='agent-steps of the CPU baseline sample (time-capped at 25 s)')
+    ap.add_argument('--cpu-agents', type=int, default=1 << 20, help='cap of the CPU baseline sample (it is sized for ~10 s per leg)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='headline measurement only')
+    ap.add_argument('--steady-steps', type=int, default=100, help='closed-loop steps before the steady-state measurement')
     ap.add_argument('--burn-in', type=int, default=3, help='closed-loop steps taken while the workload is built (SURVEY 8d config 2: "run 3 burn-in steps"), '
                                                             'so that every timed step starts from a previous solution whatever --warmup is')
     args = ap.parse_args()
@@ -116,12 +168,16 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from mpc_for_av_at_intersection_amd.batch import synthetic_batch
+    from mpc_for_av_at_intersection_amd.batch import prius_frontier, stock_routes, synthetic_batch
     from mpc_for_av_at_intersection_amd.runtime import Context
+    from mpc_for_av_at_intersection_amd import sharding
     ctx = Context(local)
-    sim = synthetic_batch(ctx, B=args.batch, A=args.agents, T=args.horizon, seed=1000 + rank)
-    if args.burn_in > 0:
-        sim.run(args.burn_in)
+    routes, dl, cd = stock_routes(ctx)
+    lo, hi = sharding.shard_instances(args.batch, rank, world)
+    A, T = args.agents, args.horizon
+
+    def make(**kw):
+        return synthetic_batch(ctx, B=args.batch, A=A, T=T, seed=1000, routes=routes, dl=dl, cd=cd, **kw)
 
     def barrier():
         torch.cuda.synchronize()
@@ -132,78 +188,182 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=ctx.device if backend == 'nccl' else 'cpu')
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=ctx.device if backend == 'nccl' else 'cpu')
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
     iters_sum = torch.zeros((), dtype=torch.float64, device=ctx.device)
     fail_sum = torch.zeros((), dtype=torch.float64, device=ctx.device)
+
+    def timed(sim, steps):
+        """EXACTLY `steps` steps between two barriers; returns (max-over-ranks seconds, mean IPM iterations, failures, qp ms, launches)"""
+        ctx.profile_qp(True); ctx.profile_qp_read()
+        iters_sum.zero_(); fail_sum.zero_()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sim.step()
+            iters_sum.add_(sim.sol['iters'].sum())
+            fail_sum.add_((sim.sol['status'] != 0).sum())
+        barrier()
+        el = time.perf_counter() - t0
+        qp_ms, qp_n = ctx.profile_qp_read()
+        ctx.profile_qp(False)
+        it = sum_over_ranks(float(iters_sum.item())); fl = sum_over_ranks(float(fail_sum.item()))
+        return max_over_ranks(el), it, fl, qp_ms / max(qp_n, 1), qp_n
+
+    # ------------------------------------------------------------------ headline: strong scaling over instances
+    sim = make(instance_slice=(lo, hi))
+    if args.burn_in > 0:
+        sim.run(args.burn_in)
     iters_sum += sim.sol['iters'].sum()              # loads torch's lazily compiled reduction kernels outside any timed region,
     fail_sum += (sim.sol['status'] != 0).sum()       # even with --warmup 0
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         sim.step()
-        iters_sum += sim.sol['iters'].sum()          # also warms up the lazily loaded torch reduction kernels
+        iters_sum += sim.sol['iters'].sum()
         fail_sum += (sim.sol['status'] != 0).sum()
     torch.cuda.synchronize()
     snap = sim.snapshot() if (rank == 0 and not args.no_cpu) else None
 
-    # HIP events around every launch of the dominant kernel (qp_kernel), recorded by the library on the stream the
-    # kernel is launched on (mpcx_profile_qp): start/stop pairs, read back after the timed region
-    ctx.profile_qp(True)
-    ctx.profile_qp_read()
+    elapsed, it_total, failures, qp_ms, qp_launches = timed(sim, args.steps)
+    P_total = args.batch * A
+    P_rank = sim.P
+    mean_iters = it_total / (P_total * args.steps)
+    value = args.batch * args.steps / elapsed
+    stage = ((T > 20 or P_rank >= 4096   # MPCX_STAGE_MIN_BATCH of csrc/mpcx_qp.hip
+              ) and os.environ.get('MPCX_QP_KERNEL') != 'wave') \
+        or os.environ.get('MPCX_QP_KERNEL') == 'stage'
+    flops_qp = qp_flops_stage(T, mean_iters) if stage else qp_flops_condensed(T, mean_iters)
+    achieved_tf = flops_qp * P_rank / (qp_ms * 1e-3) / 1e12
+    line = {
+        'metric': 'MPC timesteps/sec (whole node), N=20 horizon, 8-agent intersection, batch=4096',
+        'value': value, 'unit': 'MPC timesteps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'configs[2]/[3]: %d-agent coupled stock intersection, batch=%d instances in all (sharded over the GPUs), N=%d, '
+                               'interaction (prediction + conflict search + path cut) on-device, seeded staggered starts, %d burn-in steps'
+                               % (A, args.batch, T, args.burn_in),
+                   'instances_total': args.batch, 'instances_per_gpu': hi - lo, 'agents': A, 'horizon': T,
+                   'parallelism': 'instances sharded over %d GPU(s), no data-path collective' % world},
+        'agent_qp_per_s': value * A, 'mean_ipm_iters': mean_iters, 'qp_failures': int(failures),
+        'roofline': {'bound': 'fp64_valu', 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved_tf / FP64_PEAK_TFLOPS,
+                     'traffic': pmc_traffic_bytes() if (T == 20 and P_rank == 32768) else None,
+                     'algorithmic_bytes_per_launch': qp_launch_bytes(T, P_rank),
+                     'traffic_note': 'HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (%s), same workload' % os.path.relpath(PMC_FILE, ROOT),
+                     'kernel': ('qp_quad_kernel<8,%d> (stage-structured IPM, 8 lanes per QP)' % (2 if T <= 16 else 3 if T <= 24 else 4)) if stage
+                               else 'qp_kernel<%d> (condensed IPM, one wavefront per QP)' % T,
+                     'kernel_ms': qp_ms, 'kernel_launches_timed': qp_launches, 'flops_per_qp': flops_qp,
+                     'achieved_survey_count': qp_flops_condensed(T, mean_iters) * P_rank / (qp_ms * 1e-3) / 1e12,
+                     'frac_survey_count': qp_flops_condensed(T, mean_iters) * P_rank / (qp_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     'note': 'the kernel is pure FP64 VALU (SQ_INSTS_MFMA = 0): roof = FP64 vector rate 78.6 TFLOP/s.  achieved = flops the '
+                             'kernel\'s own algorithm needs (stage solver: O(T) Riccati sweeps, counted on its source) x measured mean IPM '
+                             'iterations x QPs per launch / HIP-event kernel time on the launch stream.  *_survey_count = the same with '
+                             'SURVEY 8(d)\'s condensed-solver count F_qp (round 1 reported that one; kept for comparison across rounds)'},
+        'roofline_hbm': {'bound': 'hbm', 'achieved': agent_step_bytes(T, A) * P_total / (elapsed / args.steps) / 1e9, 'peak': HBM_PEAK_GBS * world,
+                         'unit': 'GB/s', 'note': 'algorithmic bytes per whole step / step time; not the binding roof'},
+    }
+    line['roofline_hbm']['frac'] = line['roofline_hbm']['achieved'] / (HBM_PEAK_GBS * world)
 
-    iters_sum.zero_(); fail_sum.zero_()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.step()
-        iters_sum += sim.sol['iters'].sum()
-        fail_sum += (sim.sol['status'] != 0).sum()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    qp_total_ms, qp_launches = ctx.profile_qp_read()
-    ctx.profile_qp(False)
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device if backend == 'nccl' else 'cpu')
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    if not args.no_extras:
+        # -------------------------------------------------------------- steady state: the same batch after >= 100 closed-loop steps
+        try:
+            more = args.steady_steps - sim.steps_done
+            if more > 0:
+                sim.run(more)
+            el, it, fl, ms, _ = timed(sim, args.steps)
+            sim.check()
+            line['steady_state'] = {'value': args.batch * args.steps / el, 'unit': 'MPC timesteps/s', 'after_steps': int(sim.steps_done - args.steps),
+                                    'ms_per_step': 1e3 * el / args.steps, 'mean_ipm_iters': it / (P_total * args.steps), 'qp_failures': int(fl),
+                                    'kernel_ms': ms, 'note': 'same %d steps measurement, taken after the closed loop has run long enough '
+                                                            'for traffic to build up at the junction (paths cut, agents queueing)' % args.steps}
+            line['steady_state_value'] = line['steady_state']['value']
+        except Exception as e:                       # an extra must never take the headline line down
+            line['steady_state'] = {'error': repr(e)}
+        # -------------------------------------------------------------- A* expansion, config 5: 2^20-node Prius frontier, nodes sharded
+        try:
+            n_all = 1 << 20
+            nlo, nhi = sharding.shard_instances(n_all, rank, world)
+            model, nodes = prius_frontier(ctx, n_all, seed=0)
+            mine = nodes[nlo:nhi].contiguous()
+            out = ctx.expand(model, mine)
+            st = torch.cuda.current_stream(ctx.device)
+            reps = 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            e0.record(st)
+            for _ in range(reps):
+                ctx.expand(model, mine, out=out)
+            e1.record(st)
+            torch.cuda.synchronize()
+            ms = max_over_ranks(e0.elapsed_time(e1) / reps)
+            free_frac = sum_over_ranks(float((out['collide'] == 0).sum().item())) / (n_all * model.n_prim)
+            bytes_node = 24 + model.n_prim * (24 + 8 + 1)
+            fma_node = float(sum(model.n_pts_of) * 4 + sum(model.n_pts_of) * 3 * model.n_rows)
+            nps = n_all / (ms * 1e-3)
+            line['expand'] = {'nodes_per_s': nps, 'ms': ms, 'nodes': n_all, 'primitives': model.n_prim, 'half_plane_rows': model.n_rows,
+                              'obstacles': model.n_obst, 'free_fraction': free_frac,
+                              'algorithmic_bytes_per_node': bytes_node, 'hbm_GBps': nps * bytes_node / 1e9,
+                              'hbm_frac': nps * bytes_node / 1e9 / (HBM_PEAK_GBS * world),
+                              'fp64_fma_per_node_no_early_out': fma_node, 'fp64_equiv_frac_no_early_out': nps * fma_node * 2 / 1e12 / (FP64_PEAK_TFLOPS * world),
+                              'note': 'expand_kernel on a 2^20-node frontier (seed 0, uniform over the junction area), Prius primitives + PriusDimensions, '
+                                      'stock intersection obstacles; HIP events on the launch stream, mean of %d launches, nodes sharded evenly over the '
+                                      'GPUs (no exchange); bytes = 24 B read + P*(24+8+1) B written per node (SURVEY 8d); the FP64 figure is what the node rate would '
+                                      'cost WITHOUT early-outs (every point x row test); it can exceed 1 because exact box culling skips most tests' % reps}
+            del out, mine, nodes
+        except Exception as e:
+            line['expand'] = {'error': repr(e)}
+        # -------------------------------------------------------------- agent-sharded layout: one RCCL all-gather per step
+        if world > 1 and A % world == 0:
+            try:
+                if backend == 'nccl':
+                    sharding.init_comm(ctx, rank, world)
+                    sim_a = make(agent_shard=(rank, world), exchange='rccl')
+                else:
+                    sim_a = make(agent_shard=(rank, world), exchange=sharding.torch_exchange(world, 'cpu'))
+                sim_a.run(args.burn_in + args.warmup)
+                # the pool every rank assembled must be the one torch.distributed assembles
+                ref_pool = sharding.torch_exchange(world, None if backend == 'nccl' else 'cpu')(sim_a.obs_local.view(sim_a.B, sim_a.A, 6))
+                same = bool(torch.equal(ref_pool.reshape(-1, 6), sim_a.obs6))
+                el, it, fl, ms, _ = timed(sim_a, args.steps)
+                sim_a.check()
+                line['agent_sharded'] = {'value': args.batch * args.steps / el, 'unit': 'MPC timesteps/s', 'ms_per_step': 1e3 * el / args.steps,
+                                         'agents_per_rank': sim_a.A, 'allgather_bytes_per_rank_per_step': sim_a.P * 48,
+                                         'exchange': 'mpcx_allgather_states (RCCL over xGMI) inside mpcx_closed_loop_run' if backend == 'nccl' else 'torch.distributed %s (rehearsal)' % backend,
+                                         'pool_matches_torch_all_gather': same, 'mean_ipm_iters': it / (P_total * args.steps), 'qp_failures': int(fl)}
+                del sim_a
+            except Exception as e:
+                line['agent_sharded'] = {'error': repr(e)}
+        # -------------------------------------------------------------- weak scaling: every rank runs the whole 4096-instance batch
+        if world > 1:
+            try:
+                sim_w = make()
+                sim_w.run(args.burn_in + args.warmup)
+                el, it, fl, ms, _ = timed(sim_w, args.steps)
+                line['weak'] = {'value': world * args.batch * args.steps / el, 'unit': 'MPC timesteps/s', 'instances_per_gpu': args.batch,
+                                'ms_per_step': 1e3 * el / args.steps, 'note': 'every rank owns a full %d-instance batch' % args.batch}
+                del sim_w
+            except Exception as e:
+                line['weak'] = {'error': repr(e)}
 
     if rank == 0:
-        P = sim.P
-        qp_ms = qp_total_ms / max(qp_launches, 1)
-        mean_iters = float(iters_sum.item()) / (P * args.steps)
-        flops = qp_flops(args.horizon, mean_iters) * P
-        achieved_tf = flops / (qp_ms * 1e-3) / 1e12
-        bytes_step = agent_step_bytes(args.horizon, args.agents) * P
-        value = world * args.batch * args.steps / elapsed
-        line = {
-            'metric': 'MPC timesteps/sec (whole node), N=20 horizon, 8-agent intersection, batch=4096',
-            'value': value, 'unit': 'MPC timesteps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'configs[2]/[3]: %d-agent coupled stock intersection, batch=%d instances per GPU, N=%d, '
-                                   'interaction (prediction + conflict search + path cut) on-device, seeded staggered starts, %d burn-in steps'
-                                   % (args.agents, args.batch, args.horizon, args.burn_in),
-                       'instances_per_gpu': args.batch, 'agents': args.agents, 'horizon': args.horizon,
-                       'parallelism': 'instances sharded over %d GPU(s), no data-path collective' % world},
-            'agent_qp_per_s': value * args.agents,
-            'mean_ipm_iters': mean_iters, 'qp_failures': int(fail_sum.item()),
-            'roofline': {'bound': 'mfma', 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / FP64_PEAK_TFLOPS,
-                         'traffic': pmc_traffic_bytes() if (args.horizon == 20 and args.batch == 4096 and args.agents == 8) else None,
-                         'traffic_note': 'HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (profiles/r01_pmc_final.csv), same workload; algorithmic bytes per launch = %.3g' % (P * (32 + 2 * 32 * (args.horizon + 1) + (args.horizon + 1) + 16 * args.horizon + 32 * (args.horizon + 1) + 16 * args.horizon + 40)),
-                         'kernel': ('qp_quad_kernel<8,%d> (stage-structured IPM, 8 lanes per QP)' % (2 if args.horizon <= 16 else 3)) if ((args.horizon > 20 or args.batch * args.agents >= 4096) and os.environ.get('MPCX_QP_KERNEL') != 'wave') else 'qp_kernel<%d> (condensed IPM, one wavefront per QP)' % args.horizon,
-                         'kernel_ms': qp_ms, 'kernel_launches_timed': qp_launches, 'flops_per_qp': qp_flops(args.horizon, mean_iters),
-                         'note': 'FP64 compute roof (MI355X FP64 matrix rate == FP64 vector rate, 78.6 TFLOP/s); achieved = algorithmic flops of '
-                                 'SURVEY 8(d) (condensed, structure-exploiting count) x measured mean IPM iterations / HIP-event kernel time. The '
-                                 'stage-structured kernel executes about 0.7x that count (Riccati sweeps are O(T)), all on the FP64 VALU'},
-            'roofline_hbm': {'bound': 'hbm', 'achieved': bytes_step / (1e-3 * elapsed / args.steps * 1e3) / 1e9 * 1e3 / 1e3,
-                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'note': 'algorithmic bytes per whole step / step time; not the binding roof'},
-        }
-        line['roofline_hbm']['achieved'] = bytes_step / (elapsed / args.steps) / 1e9
-        line['roofline_hbm']['frac'] = line['roofline_hbm']['achieved'] / HBM_PEAK_GBS
         if snap is not None:
-            line['cpu_baseline'] = cpu_baseline(sim, snap, min(args.cpu_agents, P))
+            try:
+                line['cpu_baseline'] = cpu_baseline(sim, snap, args.cpu_agents)
+            except Exception as e:
+                line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))
     if world > 1:
+        barrier()
         dist.destroy_process_group()
 
 

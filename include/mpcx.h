@@ -196,7 +196,8 @@ int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state /*B,4 in-o
  * use_graph != 0 captures one step into a hipGraph on the context's stream (which must then not be the null
  * stream) and replays it n_steps times; the instantiated graph is cached in the context per descriptor. */
 typedef struct {
-    int32_t P, reserved;
+    int32_t P;
+    int32_t exchange;   /* 0: the pool obs6 is this rank's own P agents; MPCX_SHARD_AGENTS: agent-sharded multi-GPU layout, see below */
     double dl;
     double *state /*P,4*/, *applied /*P,2: (steer, accel)*/, *obs6 /*P,6 scratch*/;
     const double *path_xyyaw, *path_cs, *path_v /*or NULL*/;
@@ -207,9 +208,35 @@ typedef struct {
     double *x_sol /*P,4,T+1*/, *u_sol /*P,2,T zero-initialised*/;
     int32_t *status /*P*/, *iters /*P*/;
     double *kkt /*P,4*/;
+    /* exchange == MPCX_SHARD_AGENTS only: this rank owns agents_local agents of each of n_inst instances (P = n_inst *
+     * agents_local, agent order (instance, local agent)); the pool obs6 then has world * P rows laid out
+     * [n_inst][world * agents_local][6] and is filled every step by mpcx_allgather_states from obs_local. */
+    int32_t n_inst, agents_local;
+    double *obs_local /*P,6 scratch*/;
 } mpcx_closed_loop;
 int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *cl,
                              int32_t n_steps, int32_t use_graph);
+
+/* ---- multi-GPU exchange (the reference is single-process and has no counterpart).  One process per
+ * GPU, one communicator per context: rank 0 calls mpcx_comm_unique_id, the caller distributes the MPCX_COMM_ID_BYTES bytes
+ * to every rank by whatever means it has (torch.distributed broadcast in this package), every rank calls mpcx_comm_init.
+ * mpcx_allgather_states is ONE RCCL all-gather over xGMI of 6-double agent states (x, y, v, yaw, accel, steer), enqueued on
+ * the context's stream:
+ *   MPCX_SHARD_INSTANCES  rank r holds n_inst instances x agents_local (= all) agents; all = the rank blocks one after the other
+ *                         ([world * n_inst][agents_local][6]).  The instance-sharded data path itself needs no exchange
+ *                         (all agents of an instance are rank-local); this form serves logging / result collection.
+ *   MPCX_SHARD_AGENTS     rank r holds agents r*agents_local .. of EVERY one of n_inst instances; all = [n_inst][world *
+ *                         agents_local][6], the obstacle pool of mpcx_interaction_batch on every rank (obs_off[p] = instance *
+ *                         world * agents_local, obs_cnt[p] = world * agents_local, obs_skip[p] = the agent's own row).
+ * Without a communicator (single rank) the call is a device copy.  local and all are DEVICE pointers. */
+#define MPCX_COMM_ID_BYTES 128
+#define MPCX_SHARD_INSTANCES 1
+#define MPCX_SHARD_AGENTS 2
+int32_t mpcx_comm_unique_id(void *id /*MPCX_COMM_ID_BYTES, host*/);
+int32_t mpcx_comm_init(mpcx_ctx *ctx, int32_t world, int32_t rank, const void *id /*MPCX_COMM_ID_BYTES, host*/);
+int32_t mpcx_comm_destroy(mpcx_ctx *ctx);
+int32_t mpcx_allgather_states(mpcx_ctx *ctx, int32_t layout, int32_t n_inst, int32_t agents_local,
+                              const double *local /*n_inst,agents_local,6*/, double *all /*see layout*/);
 
 /* ---- scheduling hint for the next mpcx_qp_solve_batch calls (results never depend on it).  Interior-point iteration counts
  * are 5 for most problems with a tail to ~17, and one late-drawn hard problem ends the launch alone, so the work queue is

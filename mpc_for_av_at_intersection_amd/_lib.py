@@ -32,14 +32,20 @@ class ClosedLoopC(C.Structure):
     _PTRS = ['state', 'applied', 'obs6', 'path_xyyaw', 'path_cs', 'path_v', 'path_off', 'path_len', 'obs_off', 'obs_cnt',
              'obs_skip', 'traj_idx', 'target_ind', 'hit_idx', 'cut_len', 'hit_xy', 'xref', 'xbar', 'reaches_end',
              'x_sol', 'u_sol', 'status', 'iters', 'kkt']
-    _fields_ = [('P', C.c_int32), ('reserved', C.c_int32), ('dl', C.c_double)] + [(n, C.c_void_p) for n in _PTRS]
+    _fields_ = ([('P', C.c_int32), ('exchange', C.c_int32), ('dl', C.c_double)] + [(n, C.c_void_p) for n in _PTRS] +
+                [('n_inst', C.c_int32), ('agents_local', C.c_int32), ('obs_local', C.c_void_p)])
+
+
+COMM_ID_BYTES = 128
+SHARD_INSTANCES, SHARD_AGENTS = 1, 2
 
 
 EXPORTS = ['mpcx_create', 'mpcx_destroy', 'mpcx_last_error', 'mpcx_version', 'mpcx_set_mpc_params',
            'mpcx_qp_solve_batch', 'mpcx_mpc_prepare_batch', 'mpcx_search_model_create', 'mpcx_search_model_destroy',
            'mpcx_expand_batch', 'mpcx_interaction_batch', 'mpcx_moving_collision_batch', 'mpcx_plant_step_batch',
            'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch', 'mpcx_selftest_wave_ops', 'mpcx_selftest_mfma',
-           'mpcx_closed_loop_run', 'mpcx_profile_qp', 'mpcx_profile_qp_read', 'mpcx_set_instance_tuning', 'mpcx_set_qp_solver', 'mpcx_qp_set_order_hint', 'mpcx_expand_multi_batch']
+           'mpcx_closed_loop_run', 'mpcx_profile_qp', 'mpcx_profile_qp_read', 'mpcx_set_instance_tuning', 'mpcx_set_qp_solver', 'mpcx_qp_set_order_hint', 'mpcx_expand_multi_batch',
+           'mpcx_comm_unique_id', 'mpcx_comm_init', 'mpcx_comm_destroy', 'mpcx_allgather_states']
 
 
 def load():
@@ -87,5 +93,9 @@ def load():
     lib.mpcx_set_qp_solver.restype = i32; lib.mpcx_set_qp_solver.argtypes = [vp, i32]
     lib.mpcx_qp_set_order_hint.restype = i32; lib.mpcx_qp_set_order_hint.argtypes = [vp, vp, vp, vp]
     lib.mpcx_expand_multi_batch.restype = i32; lib.mpcx_expand_multi_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.mpcx_comm_unique_id.restype = i32; lib.mpcx_comm_unique_id.argtypes = [vp]
+    lib.mpcx_comm_init.restype = i32; lib.mpcx_comm_init.argtypes = [vp, i32, i32, vp]
+    lib.mpcx_comm_destroy.restype = i32; lib.mpcx_comm_destroy.argtypes = [vp]
+    lib.mpcx_allgather_states.restype = i32; lib.mpcx_allgather_states.argtypes = [vp, i32, i32, i32, vp, vp]
     _lib = lib
     return lib

@@ -15,21 +15,42 @@ import numpy as np
 import torch
 
 from . import _lib
-from .runtime import Context, InteractionParams, MpcParams
+from .runtime import Context, InteractionParams, MpcParams, MpcxError
 
 
 class IntersectionBatch:
     def __init__(self, ctx: Context, params: MpcParams, ip: InteractionParams, routes: Sequence[np.ndarray], dl: float,
                  route_of_agent: np.ndarray, start_index: np.ndarray, v0: Optional[np.ndarray] = None,
-                 tuning: Optional[np.ndarray] = None):
+                 tuning: Optional[np.ndarray] = None, agent_shard: Optional[tuple] = None, exchange=None):
         """routes: list of (n_r, 3) paths whose yaw column is already unwrapped (MPC.__init__, mpc.py:257);
         route_of_agent, start_index: integer arrays of shape (B, A); tuning: optional (B, 16) or (B*A, 16) array of
         MpcParams.tuning_row()s -- one cost/limit set per instance (or agent), the batched form of the reference's
-        sensitivity sweeps (scenarios/mpc_sensitivity_analysis.py)."""
+        sensitivity sweeps (scenarios/mpc_sensitivity_analysis.py).
+
+        agent_shard = (rank, world): the AGENT-SHARDED multi-GPU layout (sharding.py): this rank drives agents
+        rank*A/world .. of EVERY instance and sees the other ranks' agents only as moving obstacles, through one
+        all-gather of 6-double agent states per step.  `exchange` says who moves the rows: 'rccl' (mpcx_allgather_states
+        on the context's communicator, inside mpcx_closed_loop_run) or a callable local(B, A_loc, 6) -> pool(B, A, 6)
+        (sharding.torch_exchange: torch.distributed, used for gloo rehearsals)."""
         self.ctx, self.params, self.ip, self.dl = ctx, params, ip, float(dl)
         ctx.set_mpc_params(params)
         route_of_agent = np.asarray(route_of_agent, dtype=np.int64)
         start_index = np.asarray(start_index, dtype=np.int64)
+        self.A_total = route_of_agent.shape[1]
+        self.shard_rank, self.shard_world = (0, 1) if agent_shard is None else (int(agent_shard[0]), int(agent_shard[1]))
+        self.exchange = exchange
+        a_lo = 0
+        if agent_shard is not None:
+            if self.A_total % self.shard_world:
+                raise ValueError('agent-sharded layout: %d agents do not divide over %d ranks' % (self.A_total, self.shard_world))
+            if exchange is None and self.shard_world > 1:
+                raise ValueError('agent-sharded layout needs an exchange (\'rccl\' or a callable)')
+            a_loc = self.A_total // self.shard_world
+            a_lo = self.shard_rank * a_loc
+            route_of_agent = route_of_agent[:, a_lo:a_lo + a_loc]
+            start_index = start_index[:, a_lo:a_lo + a_loc]
+            if v0 is not None:
+                v0 = np.asarray(v0, dtype=np.float64).reshape(-1, self.A_total)[:, a_lo:a_lo + a_loc]
         self.B, self.A = route_of_agent.shape
         P = self.P = self.B * self.A
         T = params.T
@@ -51,11 +72,13 @@ class IntersectionBatch:
         self.applied = torch.zeros((P, 2), dtype=torch.float64, device=dev)      # (steer, accel) of the last step
         self.traj_idx = ctx.i32(s)
         self.target_ind = ctx.i32(s)
-        self.obs_off = ctx.i32(np.repeat(np.arange(self.B) * self.A, self.A))
-        self.obs_cnt = torch.full((P,), self.A, dtype=torch.int32, device=dev)
-        self.obs_skip = ctx.i32(np.arange(P))
+        # the obstacle pool holds ALL agents of every instance, in (instance, global agent) order; an agent skips its own row
+        self.obs_off = ctx.i32(np.repeat(np.arange(self.B) * self.A_total, self.A))
+        self.obs_cnt = torch.full((P,), self.A_total, dtype=torch.int32, device=dev)
+        self.obs_skip = ctx.i32((np.arange(self.B)[:, None] * self.A_total + a_lo + np.arange(self.A)[None, :]).reshape(-1))
         f = torch.float64
-        self.obs6 = torch.zeros((P, 6), dtype=f, device=dev)
+        self.obs6 = torch.zeros((self.B * self.A_total, 6), dtype=f, device=dev)
+        self.obs_local = torch.zeros((P, 6), dtype=f, device=dev) if agent_shard is not None else None
         # cut_len doubles as "length of the previous tmp_trajectory" (0 = none yet) for the next step
         self.inter = dict(hit_idx=torch.empty(P, dtype=torch.int32, device=dev), hit_xy=torch.empty((P, 2), dtype=f, device=dev),
                           cut_len=torch.zeros(P, dtype=torch.int32, device=dev))
@@ -72,6 +95,8 @@ class IntersectionBatch:
             tuning = np.asarray(tuning, dtype=np.float64)
             if tuning.shape == (self.B, 16):
                 tuning = np.repeat(tuning, self.A, axis=0)
+            elif agent_shard is not None and tuning.shape == (self.B * self.A_total, 16):
+                tuning = tuning.reshape(self.B, self.A_total, 16)[:, a_lo:a_lo + self.A].reshape(-1, 16)
             if tuning.shape != (P, 16):
                 raise ValueError('tuning must have shape (B, 16) or (B*A, 16)')
             self.tuning = ctx.f64(tuning)
@@ -79,7 +104,9 @@ class IntersectionBatch:
 
     def _descriptor(self) -> '_lib.ClosedLoopC':
         d = _lib.ClosedLoopC()
-        d.P, d.reserved, d.dl = self.P, 0, self.dl
+        d.P, d.exchange, d.dl = self.P, (_lib.SHARD_AGENTS if self.exchange == 'rccl' else 0), self.dl
+        d.n_inst, d.agents_local = self.B, self.A
+        d.obs_local = None if self.obs_local is None else self.obs_local.data_ptr()
         bufs = dict(state=self.state, applied=self.applied, obs6=self.obs6, path_xyyaw=self.path, path_cs=self.path_cs,
                     path_v=self.path_v, path_off=self.path_off, path_len=self.path_len, obs_off=self.obs_off,
                     obs_cnt=self.obs_cnt, obs_skip=self.obs_skip, traj_idx=self.traj_idx, target_ind=self.target_ind,
@@ -91,27 +118,55 @@ class IntersectionBatch:
             setattr(d, k, None if t is None else t.data_ptr())
         return d
 
+    def _claim_context(self):
+        """the kernels size every access from the context's horizon: another MPC / batch on the same Context may have
+        changed it since this batch was built"""
+        if self.ctx.params != self.params:
+            self.ctx.set_mpc_params(self.params)
+        self.ctx.set_instance_tuning(self.tuning)
+
     def run(self, n_steps: int, graph: bool = False):
         """n_steps of the closed loop with no host work in between (mpcx_closed_loop_run)."""
+        if callable(self.exchange):          # rehearsal exchange (torch.distributed): the host moves the rows between stages
+            for _ in range(n_steps):
+                self.step_staged()
+            return
         if self._desc is None:
             self._desc = self._descriptor()
-        self.ctx.set_instance_tuning(self.tuning)
+        self._claim_context()
         self.ctx.closed_loop_run(self.ip, self._desc, n_steps, graph)
         self.steps_done += n_steps
 
     def step(self):
         self.run(1)
 
+    def check(self):
+        """Raise where the reference raises: Exception('something wrong') of calc_nearest_index_in_direction
+        (trajectories.py:120; hit_idx -3 / target_ind -1) and the capacity limits of the interaction kernel (hit_idx -2:
+        more than MPCX_MAX_REMAINING path points ahead, MPCX_EGO_FRAMES_MAX resampled poses or MPCX_MAX_OBS obstacles)
+        -- in all of which the kernel leaves the agent's path uncut.  One small reduction + sync; call it every N steps."""
+        bad = torch.stack([(self.inter['hit_idx'] == -2).sum(), (self.inter['hit_idx'] == -3).sum(), (self.target_ind < 0).sum()]).cpu().numpy()
+        if bad.any():
+            raise MpcxError('closed loop: %d agents beyond the interaction kernel\'s capacity (hit_idx -2), %d + %d nearest-index failures '
+                            '("something wrong", trajectories.py:120) in the conflict search / reference window' % tuple(int(b) for b in bad))
+
     def step_staged(self):
         """the same step through the per-stage entry points (one host call per stage)"""
         c = self.ctx
-        c.set_instance_tuning(self.tuning)
+        self._claim_context()
         # what MovingObstacle*.get() would return for every agent: (x, y, v, yaw, a, steer)
-        self.obs6[:, 0:2] = self.state[:, 0:2]
-        self.obs6[:, 2] = self.state[:, 2]
-        self.obs6[:, 3] = self.state[:, 3]
-        self.obs6[:, 4] = self.applied[:, 1]
-        self.obs6[:, 5] = self.applied[:, 0]
+        rows = self.obs6 if self.obs_local is None else self.obs_local
+        rows[:, 0:2] = self.state[:, 0:2]
+        rows[:, 2] = self.state[:, 2]
+        rows[:, 3] = self.state[:, 3]
+        rows[:, 4] = self.applied[:, 1]
+        rows[:, 5] = self.applied[:, 0]
+        if self.obs_local is not None:       # agent-sharded: every rank assembles the whole pool
+            loc = self.obs_local.view(self.B, self.A, 6)
+            if callable(self.exchange):
+                self.obs6.copy_(self.exchange(loc).reshape(-1, 6))
+            else:
+                c.allgather_states(_lib.SHARD_AGENTS, loc, self.obs6)
         c.interaction(self.ip, self.state, self.path, self.path_cs, self.path_off, self.path_len,
                       self.inter['cut_len'], self.obs6, self.obs_off, self.obs_cnt, self.obs_skip,
                       self.traj_idx, out=self.inter)
@@ -157,9 +212,12 @@ def stock_routes(ctx: Context, pairs=((1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (3
 
 
 def synthetic_batch(ctx: Context, B: int, A: int = 8, T: int = 20, seed: int = 0, routes=None, dl=None, cd=None,
-                    max_start_frac: float = 0.35):
+                    max_start_frac: float = 0.35, instance_slice: Optional[tuple] = None, agent_shard: Optional[tuple] = None,
+                    exchange=None):
     """B instances x A agents on the stock intersection, one agent per (arm, manoeuvre)
-    route, start positions staggered along the approach (seeded), v0 = 0 as in the reference's scripts."""
+    route, start positions staggered along the approach (seeded), v0 = 0 as in the reference's scripts.
+    The workload is a function of (B, A, seed) only; a rank takes its part of it with instance_slice = (lo, hi)
+    (instance-sharded) or agent_shard = (rank, world) (agent-sharded, see IntersectionBatch)."""
     if routes is None:
         routes, dl, cd = stock_routes(ctx)
     rng = np.random.default_rng(seed)
@@ -167,7 +225,24 @@ def synthetic_batch(ctx: Context, B: int, A: int = 8, T: int = 20, seed: int = 0
     route_of_agent = np.tile(np.arange(A) % R, (B, 1))
     lens = np.array([len(r) for r in routes])[route_of_agent]
     start = (rng.random((B, A)) * max_start_frac * lens).astype(np.int64)
+    if instance_slice is not None:
+        lo, hi = instance_slice
+        route_of_agent, start = route_of_agent[lo:hi], start[lo:hi]
     params = MpcParams(T=T, L=cd.distance_back_to_front_wheel)
     ip = InteractionParams(cutoff_margin=4 * int(np.ceil(cd.radius / dl)), L=cd.distance_back_to_front_wheel, radius=cd.radius,
                            circle_centers=np.asarray(cd.circle_centers).ravel())
-    return IntersectionBatch(ctx, params, ip, routes, dl, route_of_agent, start)
+    return IntersectionBatch(ctx, params, ip, routes, dl, route_of_agent, start, agent_shard=agent_shard, exchange=exchange)
+
+
+def prius_frontier(ctx: Context, n: int = 1 << 20, seed: int = 0, extent: float = 40.0):
+    """the search model of the Prius primitives + PriusDimensions on the stock intersection and a
+    frontier of n nodes (seeded: x, y uniform over the junction area, theta ~ U[-pi, pi)) as a device tensor."""
+    from .lib.car_dimensions import PriusDimensions
+    from .lib.motion_primitive import load_motion_primitives
+    from .lib.motion_primitive_search_modified import MotionPrimitiveSearch
+    from .lib.scenario import intersection
+    cd = PriusDimensions()
+    search = MotionPrimitiveSearch(intersection(start_pos=2, turn_indicator=1), cd, load_motion_primitives('prius'), margin=cd.radius, ctx=ctx)
+    rng = np.random.default_rng(seed)
+    nodes = np.column_stack([rng.uniform(-extent, extent, n), rng.uniform(-extent, extent, n), rng.uniform(-np.pi, np.pi, n)])
+    return search._model, ctx.f64(nodes)

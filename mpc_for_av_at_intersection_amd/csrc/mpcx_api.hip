@@ -69,6 +69,8 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
+    (void)mpcx_comm_destroy(ctx);
+    if (ctx->xchg) (void)hipFree(ctx->xchg);
     delete ctx;
 }
 

@@ -33,11 +33,21 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
     // cut lengths of the previous step: the queue of the QP kernel puts the agents whose cut moved at the front
     if (hipMemcpyAsync(ctx->prev_cut, c->cut_len, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipMemcpyAsync failed");
-    mpcx::PackArgs pa{P, c->state, c->applied, c->obs6};
-    hipLaunchKernelGGL(mpcx::pack_pool_kernel, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, pa);
-    int32_t rc = mpcx_interaction_batch(ctx, ip, P, c->state, c->path_xyyaw, c->path_cs, c->path_off, c->path_len,
-                                        c->cut_len /* previous step's cut; read before it is rewritten */, P, c->obs6,
-                                        c->obs_off, c->obs_cnt, c->obs_skip, c->traj_idx, c->hit_idx, c->hit_xy, c->cut_len);
+    int32_t rc, pool_rows = P;
+    if (c->exchange == MPCX_SHARD_AGENTS) {
+        // agent-sharded layout: this rank's rows travel to every rank, every rank assembles the whole pool (one RCCL all-gather)
+        mpcx::PackArgs pa{P, c->state, c->applied, c->obs_local};
+        hipLaunchKernelGGL(mpcx::pack_pool_kernel, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, pa);
+        rc = mpcx_allgather_states(ctx, MPCX_SHARD_AGENTS, c->n_inst, c->agents_local, c->obs_local, c->obs6);
+        if (rc != MPCX_OK) return rc;
+        pool_rows = P * ctx->comm_world;
+    } else {
+        mpcx::PackArgs pa{P, c->state, c->applied, c->obs6};
+        hipLaunchKernelGGL(mpcx::pack_pool_kernel, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, pa);
+    }
+    rc = mpcx_interaction_batch(ctx, ip, P, c->state, c->path_xyyaw, c->path_cs, c->path_off, c->path_len,
+                                c->cut_len /* previous step's cut; read before it is rewritten */, pool_rows, c->obs6,
+                                c->obs_off, c->obs_cnt, c->obs_skip, c->traj_idx, c->hit_idx, c->hit_xy, c->cut_len);
     if (rc != MPCX_OK) return rc;
     rc = mpcx_mpc_prepare_batch(ctx, P, c->state, c->u_sol, c->path_xyyaw, c->path_v, c->path_off, c->cut_len, c->dl,
                                 c->target_ind, c->xref, c->reaches_end, c->xbar);
@@ -64,8 +74,16 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
         return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: null buffer in the descriptor or dl <= 0");
     if (ip->pred_steps < 1 || ip->pred_steps > MPCX_PRED_STEPS_MAX)
         return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: pred_steps outside 1..%d", MPCX_PRED_STEPS_MAX);
+    if (c->exchange != 0 && c->exchange != MPCX_SHARD_AGENTS)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: exchange must be 0 or MPCX_SHARD_AGENTS");
+    if (c->exchange == MPCX_SHARD_AGENTS) {
+        if (!c->obs_local || c->n_inst < 0 || c->agents_local < 0 || (long)c->n_inst * c->agents_local != (long)c->P)
+            return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: agent-sharded layout needs obs_local and P = n_inst * agents_local");
+        if (use_graph) return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: the agent-sharded layout (RCCL exchange) is not captured into a graph");
+    }
     // everything that allocates happens before the first launch (and outside any capture)
-    int32_t rc = mpcx_ensure_pred(ctx, (size_t)c->P * ip->pred_steps * 4);
+    const size_t pool_rows = (size_t)c->P * (c->exchange == MPCX_SHARD_AGENTS ? (size_t)ctx->comm_world : 1);
+    int32_t rc = mpcx_ensure_pred(ctx, pool_rows * ip->pred_steps * 4);
     if (rc != MPCX_OK) return rc;
     rc = mpcx_ensure_ticket(ctx);
     if (rc != MPCX_OK) return rc;
@@ -89,7 +107,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
 
     if (!ctx->stream) return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: graph replay needs a non-default stream");
     unsigned char key[sizeof ctx->loop_key];
-    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 4 * sizeof(void *) <= sizeof key,
+    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 5 * sizeof(void *) <= sizeof key,
                   "loop_key too small");
     memset(key, 0, sizeof key);
     size_t o = 0;
@@ -99,7 +117,8 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     memcpy(key + o, &ctx->pred, sizeof ctx->pred); o += sizeof ctx->pred;
     memcpy(key + o, &ctx->tune, sizeof ctx->tune); o += sizeof ctx->tune;
     memcpy(key + o, &ctx->order, sizeof ctx->order); o += sizeof ctx->order;
-    memcpy(key + o, &ctx->prev_cut, sizeof ctx->prev_cut);
+    memcpy(key + o, &ctx->prev_cut, sizeof ctx->prev_cut); o += sizeof ctx->prev_cut;
+    memcpy(key + o, &ctx->qp_solver, sizeof ctx->qp_solver);       // the captured launch is the solver chosen at capture time
     if (!ctx->loop_exec || memcmp(key, ctx->loop_key, sizeof key) != 0) {
         if (ctx->loop_exec) {
             (void)hipStreamSynchronize(ctx->stream);

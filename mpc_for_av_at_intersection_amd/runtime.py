@@ -309,6 +309,34 @@ class Context:
         self._chk(self.lib.mpcx_profile_qp_read(self._ctx, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    # ------------------------------------------------------------------ multi-GPU exchange (RCCL over xGMI)
+    def comm_unique_id(self) -> bytes:
+        """mpcx_comm_unique_id: rank 0 creates the id, the caller distributes it (sharding.init_comm broadcasts it)"""
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        rc = self.lib.mpcx_comm_unique_id(buf)
+        if rc != 0:
+            raise MpcxError('mpcx_comm_unique_id failed (%d)' % rc)
+        return buf.raw
+
+    def comm_init(self, world: int, rank: int, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        self._chk(self.lib.mpcx_comm_init(self._ctx, int(world), int(rank), buf))
+        self.comm_world, self.comm_rank = int(world), int(rank)
+
+    def comm_destroy(self):
+        self._chk(self.lib.mpcx_comm_destroy(self._ctx))
+        self.comm_world, self.comm_rank = 1, 0
+
+    def allgather_states(self, layout: int, local: torch.Tensor, out: torch.Tensor):
+        """mpcx_allgather_states: local (n_inst, agents_local, 6) -> out, laid out as include/mpcx.h describes for `layout`"""
+        n_inst, a_loc = int(local.shape[0]), int(local.shape[1])
+        self._want(local, torch.float64, (n_inst, a_loc, 6), 'local'); self._want(out, torch.float64, None, 'out')
+        world = getattr(self, 'comm_world', 1)
+        if out.numel() != world * local.numel():
+            raise MpcxError('allgather_states: out holds %d doubles, expected %d' % (out.numel(), world * local.numel()))
+        self._chk(self.lib.mpcx_allgather_states(self._ctx, int(layout), n_inst, a_loc, _ptr(local), _ptr(out)))
+        return out
+
     def synchronize(self):
         self.stream.synchronize()
 
@@ -326,6 +354,8 @@ class SearchModel:
         hp_off = np.ascontiguousarray(hp_off, np.int32)
         self.n_prim = len(templates)
         self.n_obst = len(hp_off) - 1
+        self.n_pts_of = [len(t) for t in templates]      # collision-template points per primitive
+        self.n_rows = int(len(hp))                        # half-plane rows of all obstacles
         self.edge_cost = edge_cost
         vp = C.c_void_p
         self._h = ctx.lib.mpcx_search_model_create(ctx._ctx, self.n_prim, vp(tmpl_off.ctypes.data), vp(tmpl_xy.ctypes.data),

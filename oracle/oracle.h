@@ -88,6 +88,19 @@ int32_t orc_check_collision_moving_cars(const double *centers /*nc,2*/, int32_t 
 /* collision_avoidance.py:107-119 ; -1 when nothing matches */
 int32_t orc_cutoff_idx(const double *pts /*n,3*/, int32_t n, double x, double y, double radius);
 
+/* oracle_batch.c: the whole per-agent step (scenarios/mpc_intersection.py:95-159) as one call, and a pthread driver over a batch */
+int32_t orc_agent_step(const orc_mpc_params *p, const double *full /*n,3*/, int32_t n, double dl, const double *state4,
+                       const double *obs6 /*K,6*/, int32_t K, int32_t traj_idx, int32_t prev_cut, int32_t target_ind,
+                       const double *u_warm /*2,T or NULL*/, const double *centers /*2,2*/, double radius, int32_t cutoff_margin,
+                       int32_t pred_steps, int32_t frame_window, double max_accel,
+                       int32_t *out6 /*traj_idx, cut, target_ind, hit, status, iters*/, double *x_out /*4,T+1*/, double *u_out /*2,T*/);
+int32_t orc_agent_steps_mt(int32_t n_threads, const orc_mpc_params *p, int32_t P, int32_t A,
+                           const double *path, const int32_t *path_off, const int32_t *path_len, double dl,
+                           const double *state /*P,4*/, const double *applied /*P,2*/, const double *u_warm /*P,2,T*/,
+                           const int32_t *traj_idx, const int32_t *prev_cut, const int32_t *target_ind,
+                           const double *centers, double radius, int32_t cutoff_margin, int32_t pred_steps, int32_t frame_window,
+                           double max_accel, int32_t *out6 /*P,6*/, double *x_out /*P,4,T+1*/, double *u_out /*P,2,T*/);
+
 #ifdef __cplusplus
 }
 #endif

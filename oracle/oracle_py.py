@@ -23,7 +23,7 @@ c_bp = C.POINTER(C.c_uint8)
 
 def build(force=False):
     so = os.path.join(_HERE, 'liboracle.so')
-    src = [os.path.join(_HERE, f) for f in ('oracle.c', 'oracle.h')]
+    src = [os.path.join(_HERE, f) for f in ('oracle.c', 'oracle_batch.c', 'oracle.h')]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle.so'], stdout=subprocess.DEVNULL)
     return so
@@ -46,6 +46,7 @@ def lib():
         _LIB.orc_cutoff_idx.restype = C.c_int32
         _LIB.orc_linear_model.argtypes = [C.c_double] * 5 + [c_dp] * 3
         _LIB.orc_xy_cost_mtx.argtypes = [C.c_double, c_dp]
+        _LIB.orc_agent_steps_mt.restype = C.c_int32
     return _LIB
 
 
@@ -331,3 +332,27 @@ def agent_step(p: MpcParams, full, dl, state4, obs6, traj_idx, prev_cut, target_
     sol = qp_solve(p, [x, y, v, yaw], xref, xbar, re, uw)
     return dict(traj_idx=traj_idx, hit=hit, cut=cut, target_ind=target_ind, xref=xref, xbar=xbar, re=re, sol=sol,
                 n_res=len(tres))
+
+
+def agent_steps_batch(p: MpcParams, n_threads, A, path, path_off, path_len, dl, state, applied, u_warm, traj_idx, prev_cut,
+                      target_ind, centers, radius, cutoff_margin, pred_steps=35, frame_window=20, max_accel=2.0):
+    """orc_agent_steps_mt: agent_step for every (instance, agent) pair of a captured batch state, on n_threads host threads, all
+    in C.  Agent q belongs to instance q // A and sees its A-1 instance mates as moving obstacles (x, y, v, yaw, a, steer).
+    Returns dict(out6 (P,6: traj_idx, cut, target_ind, hit, status, iters), x (P,4,T+1), u (P,2,T), threads)."""
+    P = len(state)
+    T = p.T
+    path = np.ascontiguousarray(path, np.float64)
+    po = np.ascontiguousarray(path_off, np.int32); pl = np.ascontiguousarray(path_len, np.int32)
+    st = np.ascontiguousarray(state, np.float64); ap = np.ascontiguousarray(applied, np.float64)
+    uw = np.ascontiguousarray(u_warm, np.float64).reshape(P, 2, T)
+    ti = np.ascontiguousarray(traj_idx, np.int32); pc = np.ascontiguousarray(prev_cut, np.int32); tg = np.ascontiguousarray(target_ind, np.int32)
+    ce = np.ascontiguousarray(centers, np.float64).reshape(2, 2)
+    out6 = np.zeros((P, 6), np.int32); x = np.zeros((P, 4, T + 1)); u = np.zeros((P, 2, T))
+    cp = p.c()
+    n = lib().orc_agent_steps_mt(C.c_int32(int(n_threads)), C.byref(cp), C.c_int32(P), C.c_int32(int(A)), _d(path), _i(po), _i(pl),
+                                 C.c_double(float(dl)), _d(st), _d(ap), _d(uw), _i(ti), _i(pc), _i(tg), _d(ce), C.c_double(float(radius)),
+                                 C.c_int32(int(cutoff_margin)), C.c_int32(int(pred_steps)), C.c_int32(int(frame_window)),
+                                 C.c_double(float(max_accel)), _i(out6), _d(x), _d(u))
+    if n < 1:
+        raise RuntimeError('orc_agent_steps_mt failed')
+    return dict(out6=out6, x=x, u=u, threads=n)
