@@ -322,6 +322,21 @@ def main():
             del out, mine, nodes
         except Exception as e:
             line['expand'] = {'error': repr(e)}
+        # the two multi-rank extras create a second communicator and a second batch: a rank that fails inside one of them would
+        # leave the others waiting in a collective, so a watchdog on every rank gives them a deadline, after which rank 0 prints
+        # the line it has (headline + the extras already measured) and every rank leaves
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def bail():
+                if rank == 0:
+                    line.setdefault('agent_sharded', {'error': 'deadline of 180 s exceeded (a rank failed or the exchange hung)'})
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(180.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
         # -------------------------------------------------------------- agent-sharded layout: one RCCL all-gather per step
         if world > 1 and A % world == 0:
             try:
@@ -354,6 +369,8 @@ def main():
                 del sim_w
             except Exception as e:
                 line['weak'] = {'error': repr(e)}
+        if watchdog is not None:
+            watchdog.cancel()
 
     if rank == 0:
         if snap is not None:

@@ -46,6 +46,36 @@ def test_qp_vs_oracle_golden_inputs(ctx, T):
     assert du < QP_TOL and dx < QP_TOL
 
 
+@pytest.mark.parametrize('solver', ['condensed', 'stage'])
+def test_qp_vs_exact_active_set_solution(ctx, solver):
+    """both HIP solvers against the EXACT minimiser of the literal problem of mpc.py:138-208 (tests/qp_literal.exact_solution:
+    active-set KKT solve in numpy, no code shared with oracle.c or the kernels), all 60 golden problems, T = 20"""
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams
+    from tests import qp_literal as QL
+    orc = _orc()
+    T = 20
+    g = H.gold('mpc_pre.npz')
+    ctx.set_mpc_params(MpcParams(T=T))
+    ctx.set_qp_solver(solver)
+    try:
+        st, xref, xbar, re = g['T20/state'], g['T20/xref'], g['T20/xbar'], g['T20/reaches_end']
+        out = ctx.qp_solve(ctx.f64(st), ctx.f64(xref), ctx.f64(xbar), ctx.u8(re))
+        ctx.synchronize()
+    finally:
+        ctx.set_qp_solver('auto')
+    u, x = out['u'].cpu().numpy(), out['x'].cpu().numpy()
+    assert (out['status'].cpu().numpy() == 0).all()
+    po = orc.MpcParams(T=T)
+    dist = []
+    for k in range(len(st)):
+        z = QL.pack(po, x[k], u[k])
+        ex = QL.exact_solution(po, st[k], xref[k], xbar[k], re[k], z)
+        dist.append(np.abs(z - ex['z']).max())
+    dist = np.array(dist)
+    print('%s: |z_gpu - z_exact| max %.2e median %.2e' % (solver, dist.max(), np.median(dist)))
+    assert dist.max() < 5e-5 and np.median(dist) < 1e-7
+
+
 def test_qp_warm_start_and_infeasible(ctx):
     from mpc_for_av_at_intersection_amd.runtime import MpcParams
     orc = _orc()

@@ -26,6 +26,33 @@ def test_kkt_certificate_of_literal_problem(T):
         assert c['comp'] < 1e-6 * c['grad_scale'], c     # ... that vanish on rows with slack
 
 
+@pytest.mark.parametrize('T', [10, 13, 20])
+def test_exact_active_set_solution_pins_the_oracle(T):
+    """The tightest pin available while ECOS cannot run: for EVERY golden problem the exact minimiser of the literal problem
+    (active-set KKT solve, numpy.linalg.solve, tests/qp_literal.exact_solution) and the oracle's interior-point answer.
+    The exact point is a KKT point to rounding; the oracle stops at relative residual 1e-10 * |g| with Hessian eigenvalues down
+    to 2R = 0.02, i.e. up to ~1e-5 from the optimum in the worst-conditioned problems (observed: worst 2.1e-5, median 7e-9) --
+    an order of magnitude inside the 1e-4 of the north star, and what any residual-based solver (ECOS included) delivers."""
+    g = H.gold('mpc_pre.npz')
+    p = orc.MpcParams(T=T)
+    dist = []
+    for k in range(60):
+        st, xref, xbar, re = g['T%d/state' % T][k], g['T%d/xref' % T][k], g['T%d/xbar' % T][k], g['T%d/reaches_end' % T][k]
+        sol = orc.qp_solve(p, st, xref, xbar, re)
+        assert sol.status == 0
+        zo = QL.pack(p, sol.x, sol.u)
+        ex = QL.exact_solution(p, st, xref, xbar, re, zo)
+        assert ex['eq'] < 1e-9 and ex['stat'] < 1e-7 * max(1.0, np.abs(ex['lam']).max() if len(ex['lam']) else 1.0), (k, ex['eq'], ex['stat'])
+        assert (ex['lam'] >= -1e-7).all() and ex['slack'].min() > -1e-9, k
+        P, q, c0 = QL.build(p, st, xref, xbar, re)[:3]
+        fo = float(zo @ P @ zo + q @ zo + c0)
+        assert abs(fo - ex['obj']) <= 1e-8 * max(1.0, abs(ex['obj'])), (k, fo, ex['obj'])
+        dist.append(np.abs(zo - ex['z']).max())
+    dist = np.array(dist)
+    assert dist.max() < 5e-5, dist.max()
+    assert np.median(dist) < 1e-7, np.median(dist)
+
+
 def test_against_scipy_slsqp():
     from scipy.optimize import minimize
     g = H.gold('mpc_pre.npz')
