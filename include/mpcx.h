@@ -27,8 +27,9 @@ extern "C" {
 #define MPCX_MAX_PRIM 16         /* motion primitives per search model */
 #define MPCX_MAX_OBS 16          /* moving obstacles seen by one ego */
 #define MPCX_PRED_STEPS_MAX 64   /* prediction horizon frames */
-#define MPCX_MAX_REMAINING 1024  /* path points ahead of an agent handled by mpcx_interaction_batch */
-#define MPCX_EGO_FRAMES_MAX 128  /* resampled ego poses handled by mpcx_interaction_batch */
+#define MPCX_MAX_REMAINING 1024  /* path points ahead of an agent mpcx_interaction_batch handles by default ... */
+#define MPCX_MAX_PATH_LEN 4096   /* ... and at most, when mpcx_interaction_params.max_path_len asks for more */
+#define MPCX_EGO_FRAMES_MAX 128  /* resampled ego poses: mpcx_moving_collision_batch; mpcx_interaction_batch handles capacity/4 - 128 */
 
 enum {
     MPCX_OK = 0,
@@ -120,14 +121,16 @@ int32_t mpcx_expand_multi_batch(mpcx_ctx *ctx, int32_t n_seg, const mpcx_search_
  * path_cs holds cos/sin of the path yaw column (the host computes them once per path with the same libm the
  * reference uses, so disc centres match trajectories.py:11-37 bit for bit).
  * Outputs: traj_idx (in-out, the scenario's traj_agent_idx), hit_idx (-1 = None, else index on the remaining
- * path; -2 = limits exceeded: more than MPCX_MAX_REMAINING path points ahead or MPCX_EGO_FRAMES_MAX resampled
- * poses; -3 = the reference's Exception("something wrong")), hit_xy, cut_len (length of the tmp_trajectory
+ * path; -2 = limits exceeded: more path points ahead / resampled poses than the call's capacity (max_path_len) or more than
+ * MPCX_MAX_OBS obstacles -- the agent's path is then left uncut, callers must treat it as an error (batch.check()); -3 = the reference's Exception("something wrong")), hit_xy, cut_len (length of the tmp_trajectory
  * handed to MPC.set_trajectory_fromarray). */
 typedef struct {
     int32_t pred_steps;      /* len(arange(0, TIME_HORIZON, DT)) = 35 */
     int32_t frame_window;    /* 20 */
     int32_t cutoff_margin;   /* EXTRA_CUTOFF_MARGIN = 4*ceil(radius/dl) */
-    int32_t reserved;
+    int32_t max_path_len;    /* mpcx_interaction_batch: longest path of the call in points (sizes the kernel's LDS); 0 or less than
+                              * MPCX_MAX_REMAINING = MPCX_MAX_REMAINING; at most MPCX_MAX_PATH_LEN.  Resampled ego poses handled:
+                              * capacity / 4 - 128 (128 at the default capacity) */
     double dt, L, radius;
     double circle_centers[4]; /* (x,y) of the 2 discs, car_dimensions.py:61-79 */
     double max_accel, max_speed;

@@ -33,6 +33,7 @@ class IntersectionBatch:
         on the context's communicator, inside mpcx_closed_loop_run) or a callable local(B, A_loc, 6) -> pool(B, A, 6)
         (sharding.torch_exchange: torch.distributed, used for gloo rehearsals)."""
         self.ctx, self.params, self.ip, self.dl = ctx, params, ip, float(dl)
+        ip.max_path_len = max(int(ip.max_path_len), max(len(r) for r in routes))     # sizes the interaction kernel's LDS
         ctx.set_mpc_params(params)
         route_of_agent = np.asarray(route_of_agent, dtype=np.int64)
         start_index = np.asarray(start_index, dtype=np.int64)

@@ -59,6 +59,7 @@ struct InterArgs {
     int32_t *traj_idx, *hit_idx;
     double *hit_xy;
     int32_t *cut_len;
+    int max_rem, fcap;    // capacity of this launch: path points ahead of an agent, resampled ego poses (dynamic LDS)
 };
 
 __device__ __forceinline__ double dist2d(double ax, double ay, double bx, double by) {
@@ -234,8 +235,7 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
     return first;
 }
 
-constexpr int MAXREM = MPCX_MAX_REMAINING;
-constexpr int MAXF = MPCX_EGO_FRAMES_MAX;
+constexpr int MAXF_STATIC = MPCX_EGO_FRAMES_MAX;      // moving_collision_kernel (explicit trajectories)
 
 #ifdef MPCX_INTER_PROFILE
 #define ISTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) ((unsigned long long *)(a.hit_xy + 2 * (size_t)a.P))[8 * (size_t)p + (k)] = t_ - t_last; t_last = t_; } while (0)   /* dev build: needs 8 slots per ego behind hit_xy */
@@ -243,12 +243,16 @@ constexpr int MAXF = MPCX_EGO_FRAMES_MAX;
 #define ISTAMP(k) do {} while (0)
 #endif
 __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
-    __shared__ double s_cum[MAXREM];
-    __shared__ int s_keep[MAXF];
-    static_assert(MAXF * 4 * 8 + QCAP * 2 <= MAXREM * 8, "ego discs + candidate queue reuse the cumulative-length table");
-    double (*s_ego)[4] = reinterpret_cast<double (*)[4]>(s_cum);     // ego disc centres per kept pose (x0,y0,x1,y1): written after the
-                                                                     // resampling has consumed s_cum
-    unsigned short *s_queue = reinterpret_cast<unsigned short *>(s_cum + MAXF * 4);   // candidate queue of first_conflict
+    // dynamic LDS, sized by the host from the longest path of the call (mpcx_interaction_params.max_path_len):
+    //   s_cum [max_rem] doubles   step / cumulative lengths of the remaining path; once the resampling has consumed them the
+    //                             same bytes hold s_ego [fcap][4] (ego disc centres per kept pose) and the candidate queue
+    //   s_keep [fcap] ints        indices of the kept poses
+    extern __shared__ double s_dyn[];
+    const int MAXREM = a.max_rem, MAXF = a.fcap;
+    double *s_cum = s_dyn;
+    int *s_keep = reinterpret_cast<int *>(s_dyn + MAXREM);
+    double (*s_ego)[4] = reinterpret_cast<double (*)[4]>(s_cum);
+    unsigned short *s_queue = reinterpret_cast<unsigned short *>(s_cum + (size_t)MAXF * 4);   // candidate queue of first_conflict
     __shared__ double s_box[NSEG][4];     // bounding boxes of the ego discs per run of frames
 
     const int p = blockIdx.x, lane = threadIdx.x;
@@ -516,6 +520,7 @@ struct MovArgs {
 };
 
 __global__ __launch_bounds__(64) void moving_collision_kernel(MovArgs a) {
+    constexpr int MAXF = MAXF_STATIC;
     __shared__ double s_ego[MAXF][4];
     __shared__ double s_box[NSEG][4];
     __shared__ unsigned short s_queue[QCAP];
@@ -563,9 +568,17 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
         mpcx::PredArgs pa{*ip, n_obs_pool, obs6, ctx->pred};
         hipLaunchKernelGGL(mpcx::predict_kernel, dim3((n_obs_pool + 63) / 64), dim3(64), 0, ctx->stream, pa);
     }
+    // capacity: max_path_len path points (0 = MPCX_MAX_REMAINING), rounded up to whole wavefronts; the LDS that holds their
+    // cumulative lengths later holds the ego discs of max_rem / 4 - 128 resampled poses and the 4 KB candidate queue
+    int max_rem = ip->max_path_len > MPCX_MAX_REMAINING ? ip->max_path_len : MPCX_MAX_REMAINING;
+    max_rem = (max_rem + 63) / 64 * 64;
+    if (max_rem > MPCX_MAX_PATH_LEN)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "interaction_batch: max_path_len %d exceeds %d", ip->max_path_len, MPCX_MAX_PATH_LEN);
+    const int fcap = max_rem / 4 - mpcx::QCAP * 2 / 32;
+    const size_t lds = (size_t)max_rem * sizeof(double) + (size_t)fcap * sizeof(int);
     mpcx::InterArgs ia{*ip, P, state, path_xyyaw, path_cs, path_off, path_len, prev_cut_len, ctx->pred,
-                       obs_off, obs_cnt, obs_skip, traj_idx, hit_idx, hit_xy, cut_len};
-    hipLaunchKernelGGL(mpcx::interaction_kernel, dim3(P), dim3(64), 0, ctx->stream, ia);
+                       obs_off, obs_cnt, obs_skip, traj_idx, hit_idx, hit_xy, cut_len, max_rem, fcap};
+    hipLaunchKernelGGL(mpcx::interaction_kernel, dim3(P), dim3(64), lds, ctx->stream, ia);
     return mpcx_check_launch(ctx, "interaction kernels");
 }
 

@@ -64,10 +64,11 @@ class InteractionParams:
     circle_centers: Sequence[float] = (2.18, 0.0, 0.68, 0.0)
     max_accel: float = 2.0
     max_speed: float = 30.0 / 3.6
+    max_path_len: int = 0        # longest path of the batch in points (0 = the kernel's default capacity of 1024)
 
     def to_c(self) -> _lib.InteractionParamsC:
         p = _lib.InteractionParamsC()
-        p.pred_steps, p.frame_window, p.cutoff_margin, p.reserved = int(self.pred_steps), int(self.frame_window), int(self.cutoff_margin), 0
+        p.pred_steps, p.frame_window, p.cutoff_margin, p.max_path_len = int(self.pred_steps), int(self.frame_window), int(self.cutoff_margin), int(self.max_path_len)
         p.dt, p.L, p.radius = float(self.dt), float(self.L), float(self.radius)
         p.circle_centers[:] = list(map(float, self.circle_centers))
         p.max_accel, p.max_speed = float(self.max_accel), float(self.max_speed)

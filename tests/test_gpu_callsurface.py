@@ -81,22 +81,51 @@ def test_search_prius_and_geometry_helpers():
 
 
 def test_check_collision_and_linalg_functions():
+    """lib.obstacles.check_collision / lib.linalg.transform_2d_pts (rows a10, a11) through the product call surface against
+    the COMMITTED reference outputs: the half-plane tables of tests/golden/scenarios.npz (to_convex of the reference's own
+    obstacle objects) and the per-(node, primitive) collide flags / successor poses of tests/golden/expand.npz
+    (neighbor_function of the reference on its own nodes)."""
     from mpc_for_av_at_intersection_amd.lib.linalg import create_2d_transform_mtx, transform_2d_pts
-    from mpc_for_av_at_intersection_amd.lib.obstacles import BoxObstacle, CircleObstacle, check_collision
-    box = BoxObstacle(xy_width=(2, 4), height=1, xy_center=(1, 1)).to_convex(margin=0.5)
-    assert check_collision(box, np.array([[5.0, 2.4], [5.0, 3.4]])) is True
-    assert check_collision(box, np.array([[5.0, 2.6], [5.0, 3.4]])) is False
-    circ = CircleObstacle(radius=1.0, height=1, xy_center=(0, 0)).to_convex(margin=0.0)
-    assert circ.shape == (8, 3) and check_collision(circ, np.array([[0.6], [0.6]])) is True
-    assert check_collision(circ, np.array([[0.8], [0.8]])) is False          # outside the octagon's diagonal row
-    rng = np.random.default_rng(3)
-    pts = rng.normal(size=(7, 3))
-    for cfg in ((1.0, -2.0, 0.7), (0.0, 0.0, -1.1)):
-        m = create_2d_transform_mtx(*cfg)
-        out = transform_2d_pts(cfg[2], m, pts)
-        c, s = np.cos(cfg[2]), np.sin(cfg[2])
-        ref = np.column_stack([c * pts[:, 0] - s * pts[:, 1] + cfg[0], s * pts[:, 0] + c * pts[:, 1] + cfg[1], pts[:, 2] + cfg[2]])
-        assert np.abs(out - ref).max() < 1e-14
+    from mpc_for_av_at_intersection_amd.lib.obstacles import check_collision
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive_search_modified import MotionPrimitiveSearch
+    from mpc_for_av_at_intersection_amd.lib.scenario import intersection
+    cd, mps = _setup()
+    ex, sc = H.gold('expand.npz'), H.gold('scenarios.npz')
+    sp, ti = (int(v) for v in ex['bic/scenario'])          # (start_pos, turn_indicator) of the scenario the flags were recorded on
+    tag = 'int_%d_%d' % (sp, ti)
+    hp, off = sc[tag + '/hp_bic'], sc[tag + '/hp_off']
+    scen = intersection(start_pos=sp, turn_indicator=ti)
+    # the product's obstacle objects reproduce the reference's half-plane rows bit for bit
+    mine = np.concatenate([o.to_convex(margin=cd.radius) for o in scen.obstacles], axis=0)
+    assert np.array_equal(mine, hp)
+    s = MotionPrimitiveSearch(scen, cd, mps, margin=cd.radius)
+    names = sorted(mps)
+    rng = np.random.default_rng(1)
+    col = ex['bic/collide']
+    # nodes with both outcomes among their primitives are the informative ones
+    mixed = np.nonzero((col.min(axis=1) == 0) & (col.max(axis=1) == 1))[0]
+    checked = hits = 0
+    for i in rng.choice(mixed, 6, replace=False):
+        node = tuple(ex['bic/nodes'][i].tolist())
+        for k in rng.choice(len(names), 3, replace=False):
+            pts = s.collision_checking_points_at(names[k], node)                     # transform_2d_pts of the collision template
+            flag = any(check_collision(hp[off[o]:off[o + 1]], pts[:, :2].T) for o in range(len(off) - 1))
+            assert flag == bool(col[i, k]), (i, names[k])
+            checked += 1; hits += flag
+            # successor pose = transform of the primitive's last point (motion_primitive_search.py:110-113)
+            m = create_2d_transform_mtx(*node)
+            last = transform_2d_pts(node[2], m, mps[names[k]].points[-1:].copy())
+            assert np.abs(last[0, :2] - ex['bic/nbr'][i, k, :2]).max() < 1e-12
+    assert 0 < hits < checked
+    # degenerate pose (0, 0, theta): the reference builds a 2x2 rotation-only matrix (linalg.py:13-17)
+    m = create_2d_transform_mtx(0.0, 0.0, -1.1)
+    assert m.shape == (2, 2)
+    pts = mps['straight'].points[:5].copy()
+    out = transform_2d_pts(-1.1, m, pts)
+    c, sn = np.cos(-1.1), np.sin(-1.1)
+    assert np.abs(out[:, 0] - (c * pts[:, 0] - sn * pts[:, 1])).max() < 1e-14 and np.abs(out[:, 2] - (pts[:, 2] - 1.1)).max() < 1e-14
+    with pytest.raises(AssertionError):
+        check_collision(hp[:4, :2], pts[:, :2].T)                                    # shape assertions of obstacles.py:166-170
 
 
 @pytest.mark.parametrize('T', [10, 13, 20])
