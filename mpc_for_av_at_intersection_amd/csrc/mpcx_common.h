@@ -61,6 +61,13 @@ struct QpArgs {
     int has_tune;                 // tune != NULL, tested on the host like has_warm
     const int32_t *order;         // ticket -> problem index (hard problems first) or nullptr = identity
     int has_order;
+    // second chance for problems the condensed solver gives up on (MAXITER / NUMERIC): with defer_fail it leaves their outputs
+    // untouched and appends their indices to fail_list; the stage solver then runs over that list, whose length it reads from
+    // *queue_len (has_queue_len) instead of B
+    int defer_fail;
+    int32_t *fail_list, *fail_count;
+    const int32_t *queue_len;
+    int has_queue_len;
 };
 
 void launch_qp_stage(const QpArgs &a, hipStream_t st, int n_cu);   // mpcx_qp_quad.hip

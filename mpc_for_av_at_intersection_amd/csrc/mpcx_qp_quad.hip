@@ -88,7 +88,7 @@ struct QueueSrc {
         int t = 0;
         if (cx.q == 0) t = atomicAdd(a.ticket, 1);
         t = (int)cx.gsum((double)t);                  // the other lanes contribute 0: everybody gets the leader's ticket
-        const bool have = t < a.B;
+        const bool have = t < (a.has_queue_len ? *a.queue_len : a.B);
         const int b = have ? (a.has_order ? a.order[t] : t) : 0;
         pb = at(b);
         if (TUNED) {

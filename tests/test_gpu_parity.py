@@ -76,6 +76,41 @@ def test_qp_vs_exact_active_set_solution(ctx, solver):
     assert dist.max() < 5e-5 and np.median(dist) < 1e-7
 
 
+@pytest.mark.parametrize('solver', ['condensed', 'stage', 'auto'])
+def test_qp_hard_instance_from_the_soak(ctx, solver):
+    """tests/golden/qp_hard.npz: the one QP of round 1's 120-step soak on which the condensed solver's factorisation broke down
+    short of the tolerance (status 3 -> MAX_DECEL) while the oracle and the stage solver converge.  Problems the condensed
+    solver gives up on are now re-solved by the stage solver inside the same call."""
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams
+    orc = _orc()
+    g = H.gold('qp_hard.npz')
+    T = 20
+    ctx.set_mpc_params(MpcParams(T=T))
+    po = orc.MpcParams(T=T)
+    # embedded in a batch of ordinary problems so that the second-chance list is a strict subset
+    gp = H.gold('mpc_pre.npz')
+    st = np.concatenate([gp['T20/state'][:15], g['x0'], gp['T20/state'][15:30]])
+    xref = np.concatenate([gp['T20/xref'][:15], g['xref'], gp['T20/xref'][15:30]])
+    xbar = np.concatenate([gp['T20/xbar'][:15], g['xbar'], gp['T20/xbar'][15:30]])
+    re = np.concatenate([gp['T20/reaches_end'][:15], g['reaches_end'], gp['T20/reaches_end'][15:30]])
+    uw = np.zeros((31, 2, T)); uw[15] = g['u_warm'][0]
+    ctx.set_qp_solver(solver)
+    try:
+        u_io = ctx.f64(uw)                                  # warm start and output alias, as in the closed loop
+        out = dict(x=torch.empty((31, 4, T + 1), dtype=torch.float64, device=ctx.device), u=u_io,
+                   status=torch.empty(31, dtype=torch.int32, device=ctx.device), iters=torch.empty(31, dtype=torch.int32, device=ctx.device),
+                   kkt=torch.empty((31, 4), dtype=torch.float64, device=ctx.device))
+        ctx.qp_solve(ctx.f64(st), ctx.f64(xref), ctx.f64(xbar), ctx.u8(re), u_io, out=out)
+        ctx.synchronize()
+    finally:
+        ctx.set_qp_solver('auto')
+    assert (out['status'].cpu().numpy() == 0).all(), out['status']
+    u = out['u'].cpu().numpy()
+    for k in (0, 14, 15, 16, 30):
+        sol = orc.qp_solve(po, st[k], xref[k], xbar[k], re[k], uw[k])
+        assert sol.status == 0 and np.abs(sol.u - u[k]).max() < QP_TOL, k
+
+
 def test_qp_warm_start_and_infeasible(ctx):
     from mpc_for_av_at_intersection_amd.runtime import MpcParams
     orc = _orc()
