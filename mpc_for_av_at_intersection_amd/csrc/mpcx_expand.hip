@@ -17,6 +17,11 @@ struct mpcx_search_model {
     int32_t *d_tmpl_off, *d_hp_off;
     double *d_tmpl_xy, *d_last_pose, *d_edge_cost, *d_hp;
     double *d_aabb;     // per obstacle (xlo, xhi, ylo, yhi) implied by its rows of the form (+-1, 0, c) / (0, +-1, c); +-inf if none
+    // rows NOT of that form, per obstacle (boxes: none; circle octagons: the four diagonals): the only rows the kernel evaluates
+    // arithmetically -- a point passes every axis-aligned row iff it lies in the box above (exact, see expand_block)
+    double *d_rest;
+    int32_t *d_rest_off;
+    int n_rest;
 };
 
 namespace mpcx {
@@ -27,7 +32,7 @@ constexpr int EXP_MAX_OBST = 128;
 
 struct ExpandArgs {
     int n_prim, n_obst, n_pts, n_rows, n_nodes;
-    const int32_t *tmpl_off, *hp_off;
+    const int32_t *tmpl_off, *hp_off;      // hp_off / hp: the NON-axis-aligned rows of every obstacle (mpcx_search_model::d_rest)
     const double *tmpl_xy, *last_pose, *edge_cost, *hp, *aabb, *nodes, *nodes_cs;
     double *nbr, *cost;
     uint8_t *collide;
@@ -80,10 +85,36 @@ __device__ __forceinline__ void expand_block(const ExpandArgs &a, unsigned block
         xmin = fmin(xmin, wx); xmax = fmax(xmax, wx); ymin = fmin(ymin, wy); ymax = fmax(ymax, wy);
     }
     bool hit = false;
-    for (int o = 0; o < a.n_obst && !hit; o++) {
-        if (xmin > s_aabb[4 * o + 1] || xmax < s_aabb[4 * o] || ymin > s_aabb[4 * o + 3] || ymax < s_aabb[4 * o + 2]) continue;
+    // the cull runs branch-free over all obstacles (32 at a time) into a candidate mask; only the set bits are walked.  The kernel is
+    // bound by instruction issue of divergent control flow (profiles/r02_expand_experiments.txt): a cull loop that `continue`s per
+    // lane costs every lane of the wavefront the branch code of all 24 obstacles.
+    for (int o0 = 0; o0 < a.n_obst && !hit; o0 += 32) {
+      unsigned cand = 0;
+      const int on = a.n_obst - o0 < 32 ? a.n_obst - o0 : 32;
+      for (int j = 0; j < on; j++) {
+          const double *bx = s_aabb + 4 * (o0 + j);
+          const unsigned out = (unsigned)(xmin > bx[1]) | (unsigned)(xmax < bx[0]) | (unsigned)(ymin > bx[3]) | (unsigned)(ymax < bx[2]);
+          cand |= (out ^ 1u) << j;
+      }
+      while (cand && !hit) {
+        const int o = o0 + __ffs((int)cand) - 1;
+        cand &= cand - 1;
+        const double *bx = s_aabb + 4 * o;
+        // which points pass ALL axis-aligned rows of this obstacle: a row (1, 0, c) is evaluated by the reference as
+        // fl(wx + c) <= 0, which holds iff wx <= -c (rounding never changes the sign of a sum of two doubles), so "inside the box
+        // the axis-aligned rows imply" is the same decision, taken here without branches
+        unsigned inm = 0;
+        for (int i = p0; i < p1; i++) {
+            const double px = s_xy[2 * i], py = s_xy[2 * i + 1];
+            const double wx = __dadd_rn(fma(py, -s, __dmul_rn(px, c)), tx);
+            const double wy = __dadd_rn(fma(py, c, __dmul_rn(px, s)), ty);
+            inm |= ((unsigned)(wx <= bx[1]) & (unsigned)(wx >= bx[0]) & (unsigned)(wy <= bx[3]) & (unsigned)(wy >= bx[2])) << (i - p0);
+        }
         const int r0 = s_hoff[o], r1 = s_hoff[o + 1];
-        for (int i = p0; i < p1 && !hit; i++) {
+        if (r0 == r1) { hit = inm != 0; continue; }           // a box: nothing else to test
+        while (inm && !hit) {                                  // the remaining rows (octagon diagonals, general half-planes)
+            const int i = p0 + __ffs((int)inm) - 1;
+            inm &= inm - 1;
             const double px = s_xy[2 * i], py = s_xy[2 * i + 1];
             // (x*m0 + y*m1) + t with the first product rounded and the second fused: the order OpenBLAS uses for N>=2 rows
             const double wx = __dadd_rn(fma(py, -s, __dmul_rn(px, c)), tx);
@@ -95,6 +126,7 @@ __device__ __forceinline__ void expand_block(const ExpandArgs &a, unsigned block
             }
             hit = inside;
         }
+      }
     }
     const double lx = a.last_pose[3 * k], ly = a.last_pose[3 * k + 1], lt = a.last_pose[3 * k + 2];
     double *o3 = a.nbr + (size_t)gid * 3;
@@ -163,8 +195,21 @@ extern "C" mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_
             box[4 * o] = xlo; box[4 * o + 1] = xhi; box[4 * o + 2] = ylo; box[4 * o + 3] = yhi;
         }
         m->d_aabb = to_device(box.data(), box.size());
+        std::vector<double> rest;
+        std::vector<int32_t> roff((size_t)n_obst + 1, 0);
+        for (int o = 0; o < n_obst; o++) {
+            for (int r = hp_off[o]; r < hp_off[o + 1]; r++) {
+                const double ra = hp[3 * r], rb = hp[3 * r + 1];
+                const bool axis = ((ra == 1.0 || ra == -1.0) && rb == 0.0) || (ra == 0.0 && (rb == 1.0 || rb == -1.0));
+                if (!axis) { rest.push_back(ra); rest.push_back(rb); rest.push_back(hp[3 * r + 2]); }
+            }
+            roff[(size_t)o + 1] = (int32_t)(rest.size() / 3);
+        }
+        m->n_rest = (int)(rest.size() / 3);
+        m->d_rest = to_device(rest.data(), rest.size());
+        m->d_rest_off = to_device(roff.data(), roff.size());
     }
-    if (!m->d_tmpl_off || !m->d_hp_off || !m->d_tmpl_xy || !m->d_last_pose || !m->d_edge_cost || !m->d_hp || !m->d_aabb) {
+    if (!m->d_tmpl_off || !m->d_hp_off || !m->d_tmpl_xy || !m->d_last_pose || !m->d_edge_cost || !m->d_hp || !m->d_aabb || !m->d_rest || !m->d_rest_off) {
         mpcx_fail(ctx, MPCX_E_LAUNCH, "search_model_create: device allocation failed");
         mpcx_search_model_destroy(m);
         return nullptr;
@@ -188,8 +233,8 @@ extern "C" int32_t mpcx_expand_multi_batch(mpcx_ctx *ctx, int32_t n_seg, const m
         const int n0 = seg_off[sg], n = seg_off[sg + 1] - n0;
         if (!m || n < 0 || m->n_prim != P)
             return mpcx_fail(ctx, MPCX_E_INVALID, "expand_multi_batch: segment %d has no model, a negative size or another primitive count", sg);
-        segs[sg] = mpcx::ExpandArgs{m->n_prim, m->n_obst, m->n_pts, m->n_rows, n, m->d_tmpl_off, m->d_hp_off, m->d_tmpl_xy, m->d_last_pose,
-                                    m->d_edge_cost, m->d_hp, m->d_aabb, nodes + 3 * (size_t)n0, nodes_cs ? nodes_cs + 2 * (size_t)n0 : nullptr,
+        segs[sg] = mpcx::ExpandArgs{m->n_prim, m->n_obst, m->n_pts, m->n_rest, n, m->d_tmpl_off, m->d_rest_off, m->d_tmpl_xy, m->d_last_pose,
+                                    m->d_edge_cost, m->d_rest, m->d_aabb, nodes + 3 * (size_t)n0, nodes_cs ? nodes_cs + 2 * (size_t)n0 : nullptr,
                                     nbr + 3 * (size_t)n0 * P, cost + (size_t)n0 * P, collide + (size_t)n0 * P};
         blk_first[sg] = (int32_t)blk_seg.size();
         const long long nb = ((long long)n * P + 255) / 256;
@@ -220,6 +265,7 @@ extern "C" void mpcx_search_model_destroy(mpcx_search_model *m) {
     if (!m) return;
     (void)hipFree(m->d_tmpl_off); (void)hipFree(m->d_hp_off); (void)hipFree(m->d_tmpl_xy);
     (void)hipFree(m->d_last_pose); (void)hipFree(m->d_edge_cost); (void)hipFree(m->d_hp); (void)hipFree(m->d_aabb);
+    (void)hipFree(m->d_rest); (void)hipFree(m->d_rest_off);
     delete m;
 }
 
@@ -230,8 +276,8 @@ extern "C" int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, 
     if (!m || n_nodes < 0 || !nodes || !nbr || !cost || !collide)
         return mpcx_fail(ctx, MPCX_E_INVALID, "expand_batch: null pointer or negative node count");
     if (n_nodes == 0) return MPCX_OK;
-    mpcx::ExpandArgs a{m->n_prim, m->n_obst, m->n_pts, m->n_rows, n_nodes, m->d_tmpl_off, m->d_hp_off,
-                       m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_hp, m->d_aabb, nodes, nodes_cs, nbr, cost, collide};
+    mpcx::ExpandArgs a{m->n_prim, m->n_obst, m->n_pts, m->n_rest, n_nodes, m->d_tmpl_off, m->d_rest_off,
+                       m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_rest, m->d_aabb, nodes, nodes_cs, nbr, cost, collide};
     const long long total = (long long)n_nodes * m->n_prim;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(mpcx::expand_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
