@@ -42,10 +42,12 @@
 
 // automatic choice: the stage-structured solver wins on throughput (8 problems per wavefront, O(T) work) once the batch fills
 // the chip, the condensed solver on latency (one problem per wavefront: 0.08-0.26 ms per launch up to ~1000 problems against a
-// 0.37-0.78 ms floor); measured crossover ~4096 problems for T = 13 / 20, ~6000 for T = 10.  Beyond T = 20 the condensed kernel
+// 0.37-0.78 ms floor); measured crossover on the closed-loop benchmark workload (warm starts, mean 6.2 iterations with a tail to ~20: a small batch is bound by its
+// SLOWEST problem, 37 us per iteration here against ~20 us in the condensed kernel): ~6144 problems at T = 20 (round 2: 4096 problems 0.65 vs 0.52 ms,
+// 6144 0.68 vs 0.69, 8192 0.69 vs 0.87).  Beyond T = 20 the condensed kernel
 // spills and is never competitive.
 #ifndef MPCX_STAGE_MIN_BATCH
-#define MPCX_STAGE_MIN_BATCH 4096
+#define MPCX_STAGE_MIN_BATCH 6144
 #endif
 
 namespace mpcx {
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         mu_aff = wave_sum_dpp(mu_aff) * minv;
         double sigma = mu_aff * frcp(mu);
         sigma = sigma * sigma * sigma;
-        const double smu = sigma * mu;
+        const double smu = fmax(sigma * mu, 0.1 * P.tol);       // centring target, floored: see mpcx_qp_stage.h
 
         // -------- corrector
         // second-order term damped by the affine step length (plain Mehrotra 2-cycles from boundary warm starts)
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         rat = fmax(fmax(-ds0 * is0, -dl0 * il0), fmax(-ds1 * is1, -dl1 * il1));
         rat = fmax(rat, fmax(fmax(-ds2 * is2, -dl2 * il2), fmax(-ds3 * is3, -dl3 * il3)));
         rat = wave_max_dpp(rat);
-        double alpha = (0.995 < rat) ? 0.995 * frcp(rat) : 1.0;           // min(1, 0.995/rat)
+        double alpha = (MPCX_STEP_FRACTION < rat) ? MPCX_STEP_FRACTION * frcp(rat) : 1.0;           // min(1, fraction / rat)
         // centrality safeguard (wide neighbourhood): shorten the step until min_i s_i*lam_i >= 1e-3 * mu at the new point;
         // plain Mehrotra otherwise cycles on poorly centred iterates (mu oscillates, residuals -> 0)
         for (int tr = 0; tr < 6; tr++) {
@@ -715,7 +717,7 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     if (!use_stage) {
         // The condensed solver's 64-row LDL' loses a few more digits than the Riccati recursion on the worst-conditioned problems
         // (lam/s ~ 1e10 in M = H + G'DG): about one problem in 2e6 of the benchmark workload breaks down there short of the
-        // tolerance while the stage solver (and the oracle) converge.  Those problems get a second chance: the condensed kernel
+        // tolerance while the stage solver (and a dense Cholesky on the CPU) converge.  Those problems get a second chance: the condensed kernel
         // leaves them untouched and lists them, a small stage-solver launch (a few microseconds when the list is empty) solves them.
         int32_t rc = mpcx_ensure_order(ctx, (size_t)B);
         if (rc != MPCX_OK) return rc;

@@ -57,6 +57,12 @@ struct GroupCx {
 #else
     __device__ __forceinline__ void stamp(int) const {}
 #endif
+#ifdef MPCX_STAGE_TRACE
+    double *trace_buf = nullptr;          // dev build: 8 doubles per iteration of the problem in group 0 (needs room behind kkt)
+    __device__ __forceinline__ void trace(int it, double a, double b, double c, double d, double e, double f) {
+        if (lane == 0 && trace_buf && it < 64) { double *t = trace_buf + 8 * it; t[0] = a; t[1] = b; t[2] = c; t[3] = d; t[4] = e; t[5] = f; t[6] = 1.0; }
+    }
+#endif
     __device__ __forceinline__ double ld_s(int k) const { return sh[(0 * SPL * 8 + k) * 64 + lane]; }
     __device__ __forceinline__ double ld_l(int k) const { return sh[(1 * SPL * 8 + k) * 64 + lane]; }
     __device__ __forceinline__ double ld_k(int k) const { return sh[(2 * SPL * 8 + k) * 64 + lane]; }
@@ -109,6 +115,9 @@ __global__ __launch_bounds__(64, 1) void qp_quad_kernel(QpArgs a) {
     const int lane = threadIdx.x;
     GroupCx<LQ, SPL> cx{lane & (LQ - 1), lane, (lds_double *)sh};
     QueueSrc<LQ, SPL, TUNED> src{a};
+#ifdef MPCX_STAGE_TRACE
+    if (blockIdx.x == 0) cx.trace_buf = a.kkt + 4 * (size_t)a.B;
+#endif
     mpcx_stage::solve_queue(cx, src);
 #ifdef MPCX_STAGE_PROFILE
     if (lane == 0) for (int k = 0; k < 10; k++) atomicAdd((unsigned long long *)(a.kkt + 4 * (size_t)a.B) + k, cx.t_acc[k]);   // dev build only: needs 10 spare slots behind kkt

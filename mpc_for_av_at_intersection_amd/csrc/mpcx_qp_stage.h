@@ -24,6 +24,9 @@
 #else
 #define MPCX_HD inline
 #endif
+#ifndef MPCX_STEP_FRACTION
+#define MPCX_STEP_FRACTION 0.999     /* fraction of the step to the boundary; see mpcx_common.h (the host build of this header has no other source) */
+#endif
 #define MPCX_UNROLL _Pragma("unroll")
 #define MPCX_NOUNROLL _Pragma("nounroll")
 
@@ -70,6 +73,9 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     int status = MPCX_QP_MAXITER, it = 0, loose_run = 0, max_iter = -1;
     double res_d = 0.0, res_p = 0.0, mu = 0.0;
     bool loose = false, running = false;    // uniform within a group; other groups of the wave may be in another state
+#ifdef MPCX_STAGE_TRACE
+    double trace_alpha = 0.0, trace_aff = 0.0, trace_sigma = 0.0;       // dev build: per-iteration history of one problem
+#endif
 
 #define WV(ls) (act[ls] ? (ended[ls] ? wv_end : wv_run) : 0.0)
 #define WP(ls) (act[ls] ? (ended[ls] ? wp_end : wp_run) : 0.0)
@@ -350,6 +356,9 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         for (int ls = 0; ls < SPL; ls++) rd_m = fmax(rd_m, fmax(fabs(O0[ls]), fabs(O1[ls])));
         const double n_rd = cx.gmax(rd_m), n_rp = cx.gmax(rp_m), n_mu = cx.gsum(mu_s) * minv;
         if (running) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
+#ifdef MPCX_STAGE_TRACE
+        if (running) cx.trace(it, res_d, res_p, mu, trace_alpha, trace_aff, trace_sigma);
+#endif
         cx.stamp(2);                    // [costate sweep]
         // ---- exit tests (uniform per group)
         if (running) {
@@ -532,7 +541,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 const double d = l * cx.rcp(s);
                 const double dsa = on ? -rp - row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]) : 0.0;
                 const double dla = -l - d * dsa;
-                // ratio tests: any value <= the exact ratio is a valid step bound, the 0.995 margin absorbs the seed's error
+                // ratio tests: any value <= the exact ratio is a valid step bound, the 0.001 margin of MPCX_STEP_FRACTION is 12 orders above rcp_fast's error
                 al = fmin(al, (on && dsa < 0.0) ? -s * cx.rcp_fast(dsa) : 1.0);
                 al = fmin(al, (on && dla < 0.0) ? -l * cx.rcp_fast(dla) : 1.0);
                 c1 += on ? s * dla + l * dsa : 0.0;
@@ -543,7 +552,14 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         const double mu_aff = n_mu + alpha_aff * (cx.gsum(c1) * minv) + alpha_aff * alpha_aff * (cx.gsum(c2) * minv);
         double sigma = mu_aff / (n_mu > 0.0 ? n_mu : 1.0);
         sigma = sigma * sigma * sigma;
-        const double smu = sigma * n_mu;
+        // centring target, never below a tenth of the tolerance: once mu has converged, driving it further down only worsens the
+        // conditioning (lam/s grows without bound) while the stationarity residual sits at its rounding floor -- a reversing ego on
+        // a clipped reference (tests/golden/qp_hard2.npz) lost its fourth consecutive reduced-accuracy iterate that way and ran on
+        // into garbage
+        const double smu = fmax(sigma * n_mu, 0.1 * P.tol);
+#ifdef MPCX_STAGE_TRACE
+        trace_aff = alpha_aff; trace_sigma = sigma;
+#endif
 
         cx.fence();
         cx.stamp(5);                    // [local pass C]
@@ -628,7 +644,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 am = fmin(am, (on && dl < 0.0) ? -l * cx.rcp_fast(dl) : 1e300);
             }
         cx.fence();
-        double alpha = 0.995 * cx.gmin(am);
+        double alpha = MPCX_STEP_FRACTION * cx.gmin(am);
         if (alpha > 1.0) alpha = 1.0;
         // centrality safeguard: shorten until min s*lam >= 1e-3 * mean at the new point (at most 6 times)
         for (int tr = 0; tr < 6; tr++) {
@@ -647,6 +663,9 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             if (!cx.any(running && !ok)) break;
             if (!ok) alpha *= 0.7;
         }
+#ifdef MPCX_STAGE_TRACE
+        trace_alpha = alpha;
+#endif
         cx.stamp(8);                    // [local pass E + safeguard]
         // ---- step
         if (running) {

@@ -223,6 +223,8 @@ int32_t orc_qp_build(const orc_mpc_params *p, const double *x0, const double *xr
     return r;
 }
 
+#define ORC_STEP_FRACTION 0.999
+
 /* dense Cholesky (lower), in place; returns 0 on success */
 static int chol(double *M, int n) {
     for (int j = 0; j < n; j++) {
@@ -340,9 +342,12 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
         for (int i = 0; i < m; i++) mu_aff += (s[i] + alpha * dsa[i]) * (lam[i] + alpha * dla[i]);
         mu_aff /= m;
         double sigma = mu_aff / mu; sigma = sigma * sigma * sigma;
+        /* centring target, never below a tenth of the tolerance: once mu has converged, driving it further down only worsens the
+         * conditioning of M (lam/s grows without bound) while the stationarity residual sits at its rounding floor */
+        double smu = sigma * mu; if (smu < 0.1 * p->tol) smu = 0.1 * p->tol;
         /* corrector */
         for (int i = 0; i < m; i++) {
-            rc[i] = s[i] * lam[i] + alpha * (dsa[i] * dla[i]) - sigma * mu;   /* second-order term damped by the affine step length */
+            rc[i] = s[i] * lam[i] + alpha * (dsa[i] * dla[i]) - smu;   /* second-order term damped by the affine step length */
             w[i] = (-rc[i] + lam[i] * rp[i]) / s[i];
         }
         for (int k = 0; k < n; k++) { double a = -rd[k]; for (int i = 0; i < m; i++) a -= G[i * n + k] * w[i]; du[k] = a; }
@@ -356,7 +361,9 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
             if (ds[i] < 0 && -s[i] / ds[i] < amax) amax = -s[i] / ds[i];
             if (dl[i] < 0 && -lam[i] / dl[i] < amax) amax = -lam[i] / dl[i];
         }
-        alpha = 0.995 * amax; if (alpha > 1.0) alpha = 1.0;
+        /* step to the boundary: 0.999 of the way (0.995 in round 1: on the closed-loop workload the larger fraction saves 0.8 of 6.1
+         * iterations on average, tail unchanged; same constant in both HIP solvers) */
+        alpha = ORC_STEP_FRACTION * amax; if (alpha > 1.0) alpha = 1.0;
         /* centrality safeguard (wide neighbourhood): shorten the step until min_i s_i*lam_i >= 1e-3 * mu at the new point;
          * plain Mehrotra otherwise cycles on poorly centred iterates (mu oscillates, residuals -> 0) */
         for (int tr = 0; tr < 6; tr++) {

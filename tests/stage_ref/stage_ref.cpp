@@ -18,7 +18,12 @@ struct HostCx {
     bool any(bool b) const { return b; }
     int count(bool b) const { return b ? 1 : 0; }
     double rcp(double v) const { return 1.0 / v; }
+#ifdef STAGE_REF_EMULATE_RCP
+    // the GPU's one-Newton-step reciprocal: a seed good to ~5e-8 (here: the float-rounded quotient), refined once
+    double rcp_fast(double v) const { const double r = (double)(float)(1.0 / v); return fma(fma(-v, r, 1.0), r, r); }
+#else
     double rcp_fast(double v) const { return 1.0 / v; }
+#endif
     double rcp_seed(double v) const { return 1.0 / v; }
     void fence() const {}
     void stamp(int) const {}

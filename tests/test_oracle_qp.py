@@ -80,7 +80,7 @@ def test_status_codes_and_warm_start():
     args = (g['T20/xref'][4], g['T20/xbar'][4], g['T20/reaches_end'][4])
     cold = orc.qp_solve(p, st, *args)
     warm = orc.qp_solve(p, st, *args, u_warm=np.stack([np.clip(g['T20/oa'][4], -10, 2), np.clip(g['T20/od'][4], -.78, .78)]))
-    assert cold.status == 0 and warm.status == 0 and np.abs(cold.u - warm.u).max() < 1e-8
+    assert cold.status == 0 and warm.status == 0 and np.abs(cold.u - warm.u).max() < 1e-7    # two iteration paths to the same optimum
     # boundary warm start (previous solution saturating accel bounds) must not cycle
     uw = np.zeros((2, 20)); uw[0, 0] = 2.0; uw[0, 2] = -10.0
     assert orc.qp_solve(p, st, *args, u_warm=uw).status == 0
