@@ -42,12 +42,32 @@ def qp_flops_condensed(T: int, iters: float) -> float:
 
 
 def qp_flops_stage(T: int, iters: float) -> float:
-    """FP64 flops the stage-structured solver (csrc/mpcx_qp_stage.h) needs per agent-QP, counted on its source, FMA = 2:
-    per iteration and stage: Riccati step 150 FMA + 2x2 elimination 12, costate 13, two forward sweeps 2 x 22, corrector
-    vector sweep 40, row passes 8 rows x ~36 flops; set-up per stage: two sincos (~2 x 40), weights 12, two rollouts 2 x 12."""
-    per_iter = 2 * (150 + 12 + 13 + 2 * 22 + 40) + 8 * 36
-    setup = 2 * 40 + 12 + 2 * 12
+    """FP64 flops the stage-structured solver (csrc/mpcx_qp_stage.h) needs per agent-QP, counted on its source (FMA = 2, one count
+    per stage and iteration): Riccati step 300 (G = P F 25 FMA, Phi = F'G 14, elimination + gains 40, cost-to-go update 54, +
+    adds), two forward sweeps 2 x 52, corrector vector sweep 60, costate sweep 16, four row passes over 8 rows 512 (each row:
+    gap, reciprocal, products, ratio tests), two cost-gradient evaluations 50; set-up per stage 200 (two sincos, weights, two
+    rollouts).  Recomputation (rows are recomputed where needed instead of being carried) and padding are NOT counted."""
+    per_iter = 300 + 2 * 52 + 60 + 16 + 512 + 50
+    setup = 200
     return T * (setup + iters * per_iter)
+
+
+def pmc_executed_flops(kernel='qp_quad'):
+    """FP64 flops the dominant kernel EXECUTES per launch according to the committed PMC passes: SQ_INSTS_VALU_FLOPS_FP64 (flops
+    per wavefront-instruction, FMA = 2) x mean active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU)."""
+    if not os.path.exists(PMC_FILE):
+        return None
+    v = {}
+    for line in open(PMC_FILE):
+        parts = line.strip().rsplit(',', 2)
+        if len(parts) == 3 and parts[0].startswith('mpcx::' + kernel):
+            v[parts[1]] = float(parts[2])
+    try:
+        lanes = v['SQ_THREAD_CYCLES_VALU'] / v['SQ_INSTS_VALU']
+        return dict(flops_per_launch=v['SQ_INSTS_VALU_FLOPS_FP64'] * lanes, mean_active_lanes=lanes,
+                    f64_share_of_valu=(v['SQ_INSTS_VALU_ADD_F64'] + v['SQ_INSTS_VALU_MUL_F64'] + v['SQ_INSTS_VALU_FMA_F64'] + v['SQ_INSTS_VALU_TRANS_F64']) / v['SQ_INSTS_VALU'])
+    except KeyError:
+        return None
 
 
 def agent_step_bytes(T: int, A: int) -> float:
@@ -263,6 +283,7 @@ def main():
                      'kernel': ('qp_quad_kernel<8,%d> (stage-structured IPM, 8 lanes per QP)' % (2 if T <= 16 else 3 if T <= 24 else 4)) if stage
                                else 'qp_kernel<%d> (condensed IPM, one wavefront per QP)' % T,
                      'kernel_ms': qp_ms, 'kernel_launches_timed': qp_launches, 'flops_per_qp': flops_qp,
+                     'executed_pmc': None,
                      'achieved_survey_count': qp_flops_condensed(T, mean_iters) * P_rank / (qp_ms * 1e-3) / 1e12,
                      'frac_survey_count': qp_flops_condensed(T, mean_iters) * P_rank / (qp_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                      'note': 'the kernel is pure FP64 VALU (SQ_INSTS_MFMA = 0): roof = FP64 vector rate 78.6 TFLOP/s.  achieved = flops the '
@@ -273,6 +294,13 @@ def main():
                          'unit': 'GB/s', 'note': 'algorithmic bytes per whole step / step time; not the binding roof'},
     }
     line['roofline_hbm']['frac'] = line['roofline_hbm']['achieved'] / (HBM_PEAK_GBS * world)
+    ex = pmc_executed_flops() if (stage and T == 20 and P_rank == 32768) else None
+    if ex is not None:
+        tf = ex['flops_per_launch'] / (qp_ms * 1e-3) / 1e12
+        line['roofline']['executed_pmc'] = {'tflops': tf, 'frac': tf / FP64_PEAK_TFLOPS, 'mean_active_lanes_per_valu_instruction': ex['mean_active_lanes'],
+                                            'f64_share_of_valu_instructions': ex['f64_share_of_valu'],
+                                            'note': 'lane-flops the kernel executes (committed PMC passes: SQ_INSTS_VALU_FLOPS_FP64 x mean active lanes) / live kernel time; includes '
+                                                    'recomputation, padded slots and masked work'}
 
     if not args.no_extras:
         # -------------------------------------------------------------- steady state: the same batch after >= 100 closed-loop steps
