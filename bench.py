@@ -224,20 +224,28 @@ def main():
     fail_sum = torch.zeros((), dtype=torch.float64, device=ctx.device)
 
     def timed(sim, steps):
-        """EXACTLY `steps` steps between two barriers; returns (max-over-ranks seconds, mean IPM iterations, failures, qp ms, launches)"""
+        """EXACTLY `steps` steps between two barriers; returns (max-over-ranks seconds, IPM iterations summed over ranks, failures,
+        qp ms per launch, launches, max iterations).  Iterations / failures come from the library's device-side run statistics
+        (mpcx_closed_loop_stats) or, for the staged rehearsal exchange, from torch reductions."""
+        staged = callable(sim.exchange)
         ctx.profile_qp(True); ctx.profile_qp_read()
+        ctx.closed_loop_stats(reset=True)
         iters_sum.zero_(); fail_sum.zero_()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             sim.step()
-            iters_sum.add_(sim.sol['iters'].sum())
-            fail_sum.add_((sim.sol['status'] != 0).sum())
+            if staged:
+                iters_sum.add_(sim.sol['iters'].sum())
+                fail_sum.add_((sim.sol['status'] != 0).sum())
         barrier()
         el = time.perf_counter() - t0
         qp_ms, qp_n = ctx.profile_qp_read()
         ctx.profile_qp(False)
-        it = sum_over_ranks(float(iters_sum.item())); fl = sum_over_ranks(float(fail_sum.item()))
+        st = ctx.closed_loop_stats(reset=True)
+        it_loc = float(iters_sum.item()) if staged else float(st['iterations'])
+        fl_loc = float(fail_sum.item()) if staged else float(st['failures'])
+        it = sum_over_ranks(it_loc); fl = sum_over_ranks(fl_loc)
         return max_over_ranks(el), it, fl, qp_ms / max(qp_n, 1), qp_n
 
     # ------------------------------------------------------------------ headline: strong scaling over instances

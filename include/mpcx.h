@@ -219,6 +219,10 @@ typedef struct {
 } mpcx_closed_loop;
 int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *cl,
                              int32_t n_steps, int32_t use_graph);
+/* run statistics accumulated on the device by every step of mpcx_closed_loop_run since the last reset (what the reference's scripts
+ * print per run: solver failures; plus iteration counts): out4 = (agent-steps, interior-point iterations, failed solves, max iterations).
+ * Synchronises the context's stream. */
+int32_t mpcx_closed_loop_stats(mpcx_ctx *ctx, int64_t *out4 /*host*/, int32_t reset);
 
 /* ---- multi-GPU exchange (the reference is single-process and has no counterpart).  One process per
  * GPU, one communicator per context: rank 0 calls mpcx_comm_unique_id, the caller distributes the MPCX_COMM_ID_BYTES bytes

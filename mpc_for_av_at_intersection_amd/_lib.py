@@ -45,7 +45,7 @@ EXPORTS = ['mpcx_create', 'mpcx_destroy', 'mpcx_last_error', 'mpcx_version', 'mp
            'mpcx_expand_batch', 'mpcx_interaction_batch', 'mpcx_moving_collision_batch', 'mpcx_plant_step_batch',
            'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch', 'mpcx_selftest_wave_ops', 'mpcx_selftest_mfma',
            'mpcx_closed_loop_run', 'mpcx_profile_qp', 'mpcx_profile_qp_read', 'mpcx_set_instance_tuning', 'mpcx_set_qp_solver', 'mpcx_qp_set_order_hint', 'mpcx_expand_multi_batch',
-           'mpcx_comm_unique_id', 'mpcx_comm_init', 'mpcx_comm_destroy', 'mpcx_allgather_states']
+           'mpcx_comm_unique_id', 'mpcx_comm_init', 'mpcx_comm_destroy', 'mpcx_allgather_states', 'mpcx_closed_loop_stats']
 
 
 def load():
@@ -97,5 +97,6 @@ def load():
     lib.mpcx_comm_init.restype = i32; lib.mpcx_comm_init.argtypes = [vp, i32, i32, vp]
     lib.mpcx_comm_destroy.restype = i32; lib.mpcx_comm_destroy.argtypes = [vp]
     lib.mpcx_allgather_states.restype = i32; lib.mpcx_allgather_states.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.mpcx_closed_loop_stats.restype = i32; lib.mpcx_closed_loop_stats.argtypes = [vp, C.POINTER(C.c_int64), i32]
     _lib = lib
     return lib

@@ -70,6 +70,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     (void)mpcx_comm_destroy(ctx);
+    if (ctx->stats) (void)hipFree(ctx->stats);
     if (ctx->xchg) (void)hipFree(ctx->xchg);
     delete ctx;
 }

@@ -59,7 +59,10 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
                              c->status, c->iters, c->kkt);
     ctx->order_hint = hint_before; ctx->order_now = now_before; ctx->order_prev = prev_before;
     if (rc != MPCX_OK) return rc;
-    return mpcx_plant_step_batch(ctx, P, c->state, c->u_sol, c->status, c->applied);
+    ctx->stats_iters = c->iters;
+    rc = mpcx_plant_step_batch(ctx, P, c->state, c->u_sol, c->status, c->applied);
+    ctx->stats_iters = nullptr;
+    return rc;
 }
 
 extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *c,
@@ -87,6 +90,10 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     if (rc != MPCX_OK) return rc;
     rc = mpcx_ensure_ticket(ctx);
     if (rc != MPCX_OK) return rc;
+    if (!ctx->stats) {
+        if (hipMalloc((void **)&ctx->stats, 4 * sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(ctx->stats, 0, 4 * sizeof(unsigned long long), ctx->stream) != hipSuccess)
+            return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: cannot allocate the run statistics");
+    }
     rc = mpcx_ensure_order(ctx, (size_t)c->P);
     if (rc != MPCX_OK) return rc;
     if ((size_t)c->P > ctx->prev_cut_cap) {

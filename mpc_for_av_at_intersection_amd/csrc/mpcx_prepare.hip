@@ -107,11 +107,30 @@ struct PlantArgs {
     const int32_t *status;
     double *applied;
     const mpcx_qp_tuning *tune;   // per-instance MAX_DECEL or nullptr
+    const int32_t *iters;         // closed loop only: the solver's iteration counts ...
+    unsigned long long *stats;    // ... and the run statistics they are added to: agent-steps, iterations, failed solves, max iterations
+    int has_stats;
 };
 
 // MPC.step's tail (mpc.py:294-297) + Simulation.step
 __global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.has_stats) {          // one atomic per wavefront and statistic (mpcx_closed_loop_stats)
+        const bool in = b < a.B;
+        const int it = in ? a.iters[b] : 0;
+        const int bad = (in && a.status[b] != MPCX_QP_OPTIMAL) ? 1 : 0;
+        int s_it = it, s_bad = bad, s_n = in ? 1 : 0, s_mx = it;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            s_it += __shfl_xor(s_it, d, WAVE); s_bad += __shfl_xor(s_bad, d, WAVE); s_n += __shfl_xor(s_n, d, WAVE);
+            const int o = __shfl_xor(s_mx, d, WAVE); s_mx = o > s_mx ? o : s_mx;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(a.stats + 0, (unsigned long long)s_n); atomicAdd(a.stats + 1, (unsigned long long)s_it);
+            if (s_bad) atomicAdd(a.stats + 2, (unsigned long long)s_bad);
+            atomicMax(a.stats + 3, (unsigned long long)s_mx);
+        }
+    }
     if (b >= a.B) return;
     const int T = a.p.T;
     double di = a.applied[2 * b], ai;
@@ -153,7 +172,21 @@ extern "C" int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state
     if (B == 0) return MPCX_OK;
     if (ctx->tune && ctx->tune_rows != B)
         return mpcx_fail(ctx, MPCX_E_INVALID, "plant_step_batch: %d tuning rows are set but the batch has %d agents", ctx->tune_rows, B);
-    mpcx::PlantArgs pa{ctx->mpc, B, state, u, status, applied, ctx->tune};
+    // inside mpcx_closed_loop_run the step also feeds the run statistics (ctx->stats_iters names the step's iteration counts)
+    const bool st = ctx->stats && ctx->stats_iters && status;
+    mpcx::PlantArgs pa{ctx->mpc, B, state, u, status, applied, ctx->tune, ctx->stats_iters, ctx->stats, st ? 1 : 0};
     hipLaunchKernelGGL(mpcx::plant_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, pa);
     return mpcx_check_launch(ctx, "plant_kernel");
+}
+
+extern "C" int32_t mpcx_closed_loop_stats(mpcx_ctx *ctx, int64_t *out4, int32_t reset) {
+    if (!ctx || !out4) return MPCX_E_INVALID;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (!ctx->stats) return MPCX_OK;
+    if (hipMemcpyAsync(out4, ctx->stats, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_stats: copy failed");
+    if (reset && hipMemsetAsync(ctx->stats, 0, 4 * sizeof(int64_t), ctx->stream) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_stats: reset failed");
+    return MPCX_OK;
 }

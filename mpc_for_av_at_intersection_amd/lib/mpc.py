@@ -124,7 +124,8 @@ class MPC:
         # the usual case is a prefix of the resident path (trajectory_full[:k]): only the length changes
         n = len(self.cx)
         if not (self._key() == self._dev_key and n <= self._dev_len
-                and np.array_equal(self._host_path[:n, 0], self.cx) and np.array_equal(self._host_path[:n, 2], self.cyaw)):
+                and np.array_equal(self._host_path[:n, 0], self.cx) and np.array_equal(self._host_path[:n, 1], self.cy)
+                and np.array_equal(self._host_path[:n, 2], self.cyaw)):
             self._upload()
 
     def _make_params(self) -> MpcParams:
@@ -135,6 +136,10 @@ class MPC:
 
     # ------------------------------------------------------------------ one control step (mpc.py:280-299)
     def step(self, state: State) -> Tuple[float, float]:
+        if int(globals()['MAX_ITER']) != 1:
+            # the reference re-linearises MAX_ITER times and spaces the reference window by the previous pass's speeds (mpc.py:226-237);
+            # its config has MAX_ITER = 1 and the kernels implement that one pass (window spacing from the current speed)
+            raise NotImplementedError('MAX_ITER = %r: only the single linearisation pass of the stock configuration is implemented' % (globals()['MAX_ITER'],))
         ctx = self._ctx
         p = self._make_params()
         if ctx.params != p:

@@ -276,6 +276,13 @@ class Context:
         cip = ip.to_c()
         self._chk(self.lib.mpcx_closed_loop_run(self._ctx, C.byref(cip), C.byref(desc), int(n_steps), 1 if graph else 0))
 
+    def closed_loop_stats(self, reset: bool = True):
+        """mpcx_closed_loop_stats: dict(agent_steps, iterations, failures, max_iterations) accumulated on the device by
+        closed_loop_run since the last reset (synchronises)"""
+        out = (C.c_int64 * 4)()
+        self._chk(self.lib.mpcx_closed_loop_stats(self._ctx, out, 1 if reset else 0))
+        return dict(agent_steps=int(out[0]), iterations=int(out[1]), failures=int(out[2]), max_iterations=int(out[3]))
+
     def set_instance_tuning(self, rows: Optional[torch.Tensor]):
         """mpcx_set_instance_tuning: rows (B,16) float64 device tensor (MpcParams.tuning_row per problem) or None to clear.
         The tensor is kept alive by the context while set."""

@@ -115,3 +115,24 @@ def test_degenerate_paths_and_no_obstacles(ctx):
                           ctx.f64(pool), ctx.i32([0]), ctx.i32([20]), None, ctx.i32([0]))
     ctx.synchronize()
     assert int(out['hit_idx'].cpu()[0]) == -2
+
+
+def test_closed_loop_run_statistics():
+    """mpcx_closed_loop_stats: the device-side counters of mpcx_closed_loop_run (agent-steps, iterations, failures, max iterations)
+    equal what the per-step outputs add up to"""
+    from mpc_for_av_at_intersection_amd.batch import synthetic_batch
+    from mpc_for_av_at_intersection_amd.runtime import Context
+    ctx = Context(0)
+    sim = synthetic_batch(ctx, B=40, A=8, T=20, seed=9)
+    ctx.closed_loop_stats(reset=True)
+    it_sum = fails = it_max = 0
+    for _ in range(7):
+        sim.step()
+        it = sim.sol['iters'].cpu().numpy(); st = sim.sol['status'].cpu().numpy()
+        it_sum += int(it.sum()); fails += int((st != 0).sum()); it_max = max(it_max, int(it.max()))
+    s = ctx.closed_loop_stats(reset=True)
+    assert s == dict(agent_steps=7 * sim.P, iterations=it_sum, failures=fails, max_iterations=it_max), s
+    sim.run(3)
+    s = ctx.closed_loop_stats(reset=False)
+    assert s['agent_steps'] == 3 * sim.P and ctx.closed_loop_stats()['agent_steps'] == 3 * sim.P
+    assert ctx.closed_loop_stats()['agent_steps'] == 0
