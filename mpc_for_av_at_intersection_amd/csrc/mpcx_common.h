@@ -205,30 +205,47 @@ __device__ __forceinline__ double pt_dist(const double *path, int idx, double x,
     return __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
 }
 
-// trajectories.py:100-126 on path[start .. n) ; returns absolute index or -1 ("something wrong")
+// trajectories.py:100-126 on path[start .. n) ; returns absolute index or -1 ("something wrong").
+// The three smallest (distance, index) pairs in ascending order, ties by lower index (= numpy's argpartition + argsort on these
+// data): ONE pass over the points keeps each lane's three smallest (the next 64 points are in flight meanwhile; the square root is
+// taken only where the squared distance could enter the lane's three: sqrt is monotone), then the wave-wide minimum is popped
+// three times.  Round 1 made three passes with a square root per point each.
 __device__ inline int nearest_index_in_direction(const double *path, int n, int start, double x, double y, int lane) {
     const int len = n - start;
     if (len <= 1) return start;
     if (len == 2) return start + 1;
-    int bi[3];
-    double bd[3];
-    // three passes of (distance, index)-argmin == the three smallest in ascending order, ties by lower index
-#pragma unroll
-    for (int pass = 0; pass < 3; pass++) {
-        double d = INFINITY;
-        int ix = 0x7fffffff;
-        for (int i = lane; i < len; i += WAVE) {
-            bool skip = (pass >= 1 && i == bi[0]) || (pass >= 2 && i == bi[1]);
-            double di = pt_dist(path, start + i, x, y);
-            bool take = !skip && ((di < d) || (di == d && i < ix));
-            d = take ? di : d;
-            ix = take ? i : ix;
+    double b0d = INFINITY, b1d = INFINITY, b2d = INFINITY, b2s = INFINITY, b1s = INFINITY, b0s = INFINITY;
+    int b0i = 0x7fffffff, b1i = 0x7fffffff, b2i = 0x7fffffff;
+    double cx = 0.0, cy = 0.0;
+    if (lane < len) { const double *q = path + 3 * (size_t)(start + lane); cx = q[0]; cy = q[1]; }
+    for (int i0 = 0; i0 < len; i0 += WAVE) {
+        const int i = i0 + lane;
+        double nx = 0.0, ny = 0.0;
+        if (i + WAVE < len) { const double *q = path + 3 * (size_t)(start + i + WAVE); nx = q[0]; ny = q[1]; }
+        if (i < len) {
+            const double dx = __dadd_rn(cx, -x), dy = __dadd_rn(cy, -y);
+            const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+            if (d2 < b2s || b2i == 0x7fffffff) {
+                const double d = __dsqrt_rn(d2);
+                if (d < b2d || (d == b2d && i < b2i)) {
+                    if (d < b1d || (d == b1d && i < b1i)) {
+                        b2d = b1d; b2i = b1i; b2s = b1s;
+                        if (d < b0d || (d == b0d && i < b0i)) { b1d = b0d; b1i = b0i; b1s = b0s; b0d = d; b0i = i; b0s = d2; }
+                        else { b1d = d; b1i = i; b1s = d2; }
+                    } else { b2d = d; b2i = i; b2s = d2; }
+                }
+            }
         }
-        wave_argmin(d, ix);
-        bd[pass] = d;
-        bi[pass] = ix;
+        cx = nx; cy = ny;
     }
-    (void)bd;
+    int bi[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {     // pop the wave-wide minimum three times
+        double d = b0d; int ix = b0i;
+        wave_argmin(d, ix);
+        bi[r] = ix;
+        if (b0i == ix) { b0d = b1d; b0i = b1i; b1d = b2d; b1i = b2i; b2d = INFINITY; b2i = 0x7fffffff; }
+    }
     if (abs(bi[1] - bi[2]) == 2) return bi[0] + start;
     if (abs(bi[0] - bi[1]) == 1) return max(bi[0], bi[1]) + start;
     return -1;

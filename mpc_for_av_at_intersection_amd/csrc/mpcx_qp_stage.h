@@ -162,6 +162,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         }
     };
     auto row_on = [&](int ls, int r) -> bool { return (r == 4 || r == 5) ? rate[ls] : act[ls]; };
+    // slacks and multipliers of one slot, all 16 loads in flight before the first is used (left to itself the compiler loads each
+    // row right before its use and waits for it: 24 exposed LDS round trips per pass at one wavefront per SIMD)
+    auto rows_of = [&](int ls, double (&sv)[ROWS], double (&lv)[ROWS]) {
+        MPCX_UNROLL
+        for (int r = 0; r < ROWS; r++) { sv[r] = cx.ld_s(ls * ROWS + r); lv[r] = cx.ld_l(ls * ROWS + r); }
+    };
     // gradient of the cost (no multipliers) wrt x_{t+1} and u_t at the current iterate; recomputed where needed rather than
     // kept across the Riccati sweep (30 doubles per lane that the sweep needs for the cost-to-go)
     auto cost_grad = [&](double (&G0)[SPL], double (&G1)[SPL], double (&G2)[SPL], double (&G3)[SPL], double (&H0)[SPL], double (&H1)[SPL]) {
@@ -312,11 +318,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         cost_grad(PG0, PG1, PG2, PG3, PH0, PH1);
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++) {
-            double lam[ROWS], nu[ROWS], dd[ROWS];
+            double lam[ROWS], nu[ROWS], dd[ROWS], sv[ROWS], lv[ROWS];
+            rows_of(ls, sv, lv);
             MPCX_UNROLL
             for (int r = 0; r < ROWS; r++) {
                 const bool on = row_on(ls, r);
-                const double s = cx.ld_s(ls * ROWS + r), l = cx.ld_l(ls * ROWS + r);
+                const double s = sv[r], l = lv[r];
                 const double is = cx.rcp(s);
                 const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
                 const double d = on ? l * is : 0.0;
@@ -483,12 +490,17 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             for (int turn = 0; turn < NTURN; turn++) {
                 if (q == turn) {
+                    double kk[SPL][8];           // this lane's gains, all in flight before the first is used
+                    MPCX_UNROLL
+                    for (int ls = 0; ls < SPL; ls++)
+                        MPCX_UNROLL
+                        for (int c = 0; c < 8; c++) kk[ls][c] = cx.ld_k(ls * 8 + c);
                     MPCX_UNROLL
                     for (int ls = 0; ls < SPL; ls++) {
                         {
                             double da = k0[ls], dd = k1[ls];
                             MPCX_UNROLL
-                            for (int c = 0; c < 4; c++) { da += cx.ld_k(ls * 8 + c) * z[c]; dd += cx.ld_k(ls * 8 + 4 + c) * z[c]; }
+                            for (int c = 0; c < 4; c++) { da += kk[ls][c] * z[c]; dd += kk[ls][4 + c] * z[c]; }
                             {
                                 double ka4, ka5, kd4, kd5;
                                 prev_block(ls, ka4, ka5, kd4, kd5);
@@ -532,11 +544,13 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         double al = 1.0, c1 = 0.0, c2 = 0.0;
         // per row, recomputed from (s, lam, u, x) wherever needed instead of being kept: rp = s + gap, d = lam / s
         MPCX_UNROLL
-        for (int ls = 0; ls < SPL; ls++)
+        for (int ls = 0; ls < SPL; ls++) {
+            double sv[ROWS], lv[ROWS];
+            rows_of(ls, sv, lv);
             MPCX_UNROLL
             for (int r = 0; r < ROWS; r++) {
                 const bool on = row_on(ls, r);
-                const double s = cx.ld_s(ls * ROWS + r), l = on ? cx.ld_l(ls * ROWS + r) : 0.0;
+                const double s = sv[r], l = on ? lv[r] : 0.0;
                 const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
                 const double d = l * cx.rcp(s);
                 const double dsa = on ? -rp - row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]) : 0.0;
@@ -547,6 +561,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 c1 += on ? s * dla + l * dsa : 0.0;
                 c2 += dsa * dla;
             }
+        }
         const double alpha_aff = cx.gmin(al);
         // mu_aff = sum (s + a dsa)(lam + a dla) / m = mu + a c1/m + a^2 c2/m
         const double mu_aff = n_mu + alpha_aff * (cx.gsum(c1) * minv) + alpha_aff * alpha_aff * (cx.gsum(c2) * minv);
@@ -570,11 +585,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             double C01[SPL], C23[SPL], C45[SPL], C67[SPL], C45n[SPL];
             MPCX_UNROLL
             for (int ls = 0; ls < SPL; ls++) {
-                double nu[ROWS];
+                double nu[ROWS], sv[ROWS], lv[ROWS];
+                rows_of(ls, sv, lv);
                 MPCX_UNROLL
                 for (int r = 0; r < ROWS; r++) {
                     const bool on = row_on(ls, r);
-                    const double s = cx.ld_s(ls * ROWS + r), l = on ? cx.ld_l(ls * ROWS + r) : 0.0;
+                    const double s = sv[r], l = on ? lv[r] : 0.0;
                     const double is = cx.rcp(s);
                     const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
                     const double dsa = on ? -rp - row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]) : 0.0;
@@ -593,6 +609,11 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             double pv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             for (int turn = NTURN - 1; turn >= 0; turn--) {
                 if (q == turn) {
+                    double kk[SPL][8];           // this lane's gains, all in flight before the first is used
+                    MPCX_UNROLL
+                    for (int ls = 0; ls < SPL; ls++)
+                        MPCX_UNROLL
+                        for (int c = 0; c < 8; c++) kk[ls][c] = cx.ld_k(ls * 8 + c);
                     MPCX_UNROLL
                     for (int ls = SPL - 1; ls >= 0; ls--) {
                         const double g0 = pv[0] + CG0[ls], g1 = pv[1] + CG1[ls], g2 = pv[2] + CG2[ls], g3 = pv[3] + CG3[ls];
@@ -604,7 +625,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                         KC0[ls] = k0; KC1[ls] = k1;
                         const double hz[6] = {g0, g1, A0[ls] * g0 + A2[ls] * g1 + g2, A1[ls] * g0 + A3[ls] * g1 + g3, 0.0, 0.0};
                         MPCX_UNROLL
-                        for (int i = 0; i < 4; i++) pv[i] = hz[i] + cx.ld_k(ls * 8 + i) * hu0 + cx.ld_k(ls * 8 + 4 + i) * hu1;
+                        for (int i = 0; i < 4; i++) pv[i] = hz[i] + kk[ls][i] * hu0 + kk[ls][4 + i] * hu1;
                         {
                             double ka4, ka5, kd4, kd5;
                             prev_block(ls, ka4, ka5, kd4, kd5);
@@ -632,17 +653,20 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             return on ? -rp - row_dir(r, D0[ls], D1[ls], Dp[ls], E2[ls]) : 0.0;
         };
         MPCX_UNROLL
-        for (int ls = 0; ls < SPL; ls++)
+        for (int ls = 0; ls < SPL; ls++) {
+            double sv[ROWS], lv[ROWS];
+            rows_of(ls, sv, lv);
             MPCX_UNROLL
             for (int r = 0; r < ROWS; r++) {
                 const bool on = row_on(ls, r);
-                const double s = cx.ld_s(ls * ROWS + r), l = on ? cx.ld_l(ls * ROWS + r) : 0.0;
+                const double s = sv[r], l = on ? lv[r] : 0.0;
                 const double ds = slack_step(ls, r, s);
                 const double dl = on ? -RC[ls][r] - (l * cx.rcp(s)) * ds : 0.0;
                 cx.st_k(ls * ROWS + r, dl);
                 am = fmin(am, (on && ds < 0.0) ? -s * cx.rcp_fast(ds) : 1e300);
                 am = fmin(am, (on && dl < 0.0) ? -l * cx.rcp_fast(dl) : 1e300);
             }
+        }
         cx.fence();
         double alpha = MPCX_STEP_FRACTION * cx.gmin(am);
         if (alpha > 1.0) alpha = 1.0;
@@ -650,14 +674,19 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         for (int tr = 0; tr < 6; tr++) {
             double pmin = 1e300, psum = 0.0;
             MPCX_UNROLL
-            for (int ls = 0; ls < SPL; ls++)
+            for (int ls = 0; ls < SPL; ls++) {
+                double sv[ROWS], lv[ROWS], dv[ROWS];
+                rows_of(ls, sv, lv);
+                MPCX_UNROLL
+                for (int r = 0; r < ROWS; r++) dv[r] = cx.ld_k(ls * ROWS + r);
                 MPCX_UNROLL
                 for (int r = 0; r < ROWS; r++) {
                     const bool on = row_on(ls, r);
-                    const double s = cx.ld_s(ls * ROWS + r), l = cx.ld_l(ls * ROWS + r);
-                    const double pr = (s + alpha * slack_step(ls, r, s)) * (l + alpha * cx.ld_k(ls * ROWS + r));
+                    const double s = sv[r], l = lv[r];
+                    const double pr = (s + alpha * slack_step(ls, r, s)) * (l + alpha * dv[r]);
                     pmin = fmin(pmin, on ? pr : 1e300); psum += on ? pr : 0.0;
                 }
+            }
             const double gmn = cx.gmin(pmin), gsm = cx.gsum(psum);
             const bool ok = gmn >= 1e-3 * (gsm * minv);
             if (!cx.any(running && !ok)) break;
@@ -669,14 +698,19 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         cx.stamp(8);                    // [local pass E + safeguard]
         // ---- step
         if (running) {
-            MPCX_UNROLL
-            for (int ls = 0; ls < SPL; ls++)
+            {
+                double sv[SPL * ROWS], lv[SPL * ROWS], dv[SPL * ROWS];       // every load in flight before the first store
                 MPCX_UNROLL
-                for (int r = 0; r < ROWS; r++) {          // rows that are off have ds = dl = 0
-                    const double s = cx.ld_s(ls * ROWS + r);
-                    cx.st_s(ls * ROWS + r, s + alpha * slack_step(ls, r, s));
-                    cx.st_l(ls * ROWS + r, cx.ld_l(ls * ROWS + r) + alpha * cx.ld_k(ls * ROWS + r));
-                }
+                for (int k = 0; k < SPL * ROWS; k++) { sv[k] = cx.ld_s(k); lv[k] = cx.ld_l(k); dv[k] = cx.ld_k(k); }
+                MPCX_UNROLL
+                for (int ls = 0; ls < SPL; ls++)
+                    MPCX_UNROLL
+                    for (int r = 0; r < ROWS; r++) {          // rows that are off have ds = dl = 0
+                        const double s = sv[ls * ROWS + r];
+                        cx.st_s(ls * ROWS + r, s + alpha * slack_step(ls, r, s));
+                        cx.st_l(ls * ROWS + r, lv[ls * ROWS + r] + alpha * dv[ls * ROWS + r]);
+                    }
+            }
             MPCX_UNROLL
             for (int ls = 0; ls < SPL; ls++) {
                 U0[ls] += alpha * D0[ls]; U1[ls] += alpha * D1[ls];
