@@ -29,7 +29,7 @@ extern "C" {
 #define MPCX_PRED_STEPS_MAX 64   /* prediction horizon frames */
 #define MPCX_MAX_REMAINING 1024  /* path points ahead of an agent mpcx_interaction_batch handles by default ... */
 #define MPCX_MAX_PATH_LEN 4096   /* ... and at most, when mpcx_interaction_params.max_path_len asks for more */
-#define MPCX_EGO_FRAMES_MAX 128  /* resampled ego poses: mpcx_moving_collision_batch; mpcx_interaction_batch handles capacity/4 - 128 */
+#define MPCX_EGO_FRAMES_MAX 128  /* resampled ego poses: mpcx_moving_collision_batch; mpcx_interaction_batch handles capacity/4 - 32 */
 
 enum {
     MPCX_OK = 0,
@@ -128,9 +128,9 @@ typedef struct {
     int32_t pred_steps;      /* len(arange(0, TIME_HORIZON, DT)) = 35 */
     int32_t frame_window;    /* 20 */
     int32_t cutoff_margin;   /* EXTRA_CUTOFF_MARGIN = 4*ceil(radius/dl) */
-    int32_t max_path_len;    /* mpcx_interaction_batch: longest path of the call in points (sizes the kernel's LDS); 0 or less than
-                              * MPCX_MAX_REMAINING = MPCX_MAX_REMAINING; at most MPCX_MAX_PATH_LEN.  Resampled ego poses handled:
-                              * capacity / 4 - 128 (128 at the default capacity) */
+    int32_t max_path_len;    /* mpcx_interaction_batch: longest path of the call in points (sizes the kernel's LDS: state it exactly,
+                              * resident wavefronts hide the kernel's latency); 0 = MPCX_MAX_REMAINING; at least 512, at most
+                              * MPCX_MAX_PATH_LEN.  Resampled ego poses handled: capacity / 4 - 32 */
     double dt, L, radius;
     double circle_centers[4]; /* (x,y) of the 2 discs, car_dimensions.py:61-79 */
     double max_accel, max_speed;

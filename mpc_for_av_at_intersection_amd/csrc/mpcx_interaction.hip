@@ -97,7 +97,7 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // at a time, one (position, run) pair per lane with a uniform trip count -- no lane idles behind its neighbour's nested loops
 // (round 1: one position per lane through all runs; 7/8 of the issue slots of that loop ran with a handful of live lanes).
 constexpr int NSEG = 8;
-constexpr int QCAP = MPCX_MAX_OBS * MPCX_PRED_STEPS_MAX * 2;     // every candidate of one chunk fits
+constexpr int QCAP = 8 * WAVE;      // a run's queue holds at most the candidates of one chunk (8 per lane)
 __device__ __forceinline__ double grp8_min(double v) {
     v = fmin(v, dpp_mov<0xB1>(v, v)); v = fmin(v, dpp_mov<0x4E>(v, v)); v = fmin(v, dpp_mov<0x141>(v, v));
     return v;
@@ -568,9 +568,12 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
         mpcx::PredArgs pa{*ip, n_obs_pool, obs6, ctx->pred};
         hipLaunchKernelGGL(mpcx::predict_kernel, dim3((n_obs_pool + 63) / 64), dim3(64), 0, ctx->stream, pa);
     }
-    // capacity: max_path_len path points (0 = MPCX_MAX_REMAINING), rounded up to whole wavefronts; the LDS that holds their
-    // cumulative lengths later holds the ego discs of max_rem / 4 - 128 resampled poses and the 4 KB candidate queue
-    int max_rem = ip->max_path_len > MPCX_MAX_REMAINING ? ip->max_path_len : MPCX_MAX_REMAINING;
+    // capacity: max_path_len path points (0 = MPCX_MAX_REMAINING; never below 512), rounded up to whole wavefronts; the LDS that
+    // holds their cumulative lengths later holds the ego discs of max_rem / 4 - 32 resampled poses and the 1 KB candidate queue.
+    // The kernel hides its memory latency with resident wavefronts (17 -> 11 blocks per CU costs 36 %), so the LDS follows the
+    // call's longest path instead of a fixed 1024 points.
+    int max_rem = ip->max_path_len > 0 ? ip->max_path_len : MPCX_MAX_REMAINING;
+    if (max_rem < 512) max_rem = 512;
     max_rem = (max_rem + 63) / 64 * 64;
     if (max_rem > MPCX_MAX_PATH_LEN)
         return mpcx_fail(ctx, MPCX_E_INVALID, "interaction_batch: max_path_len %d exceeds %d", ip->max_path_len, MPCX_MAX_PATH_LEN);

@@ -190,6 +190,23 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     // initial point (same rules as the condensed solver).  With have == false everything is zeroed, so the group idles harmlessly.
     auto setup = [&]() {
         const bool valid = have;
+        // every global load of the new problem is issued here, before anything waits for one (the refill is run ~16 times per
+        // wavefront with all eight groups waiting for it; the reference window used to be read twice, each time behind a sweep)
+        double in_vb[SPL], in_ph[SPL], in_yr[SPL], in_r0[SPL], in_r1[SPL], in_r2[SPL], in_u0[SPL], in_u1[SPL];
+        bool in_end[SPL], in_uend[SPL];
+        MPCX_UNROLL
+        for (int ls = 0; ls < SPL; ls++) {
+            const int t = q * SPL + ls;
+            const bool a_ = valid && t < T;
+            const int tc = a_ ? t : 0;
+            const int tn = t + 1 <= T ? t + 1 : T;          // slots beyond the horizon read a valid column; their weights are zero
+            in_vb[ls] = a_ ? pb.xbar[2 * W + tc] : 0.0; in_ph[ls] = a_ ? pb.xbar[3 * W + tc] : 0.0;
+            in_end[ls] = a_ ? (pb.re[tc + 1] != 0) : false; in_uend[ls] = a_ ? (pb.re[tc] != 0) : false;
+            in_r0[ls] = valid ? pb.xref[0 * W + tn] : 0.0; in_r1[ls] = valid ? pb.xref[1 * W + tn] : 0.0;
+            in_r2[ls] = valid ? pb.xref[2 * W + tn] : 0.0; in_yr[ls] = valid ? pb.xref[3 * W + tn] : 0.0;
+            in_u0[ls] = (a_ && pb.u_warm) ? pb.u_warm[tc] : 0.0;
+            in_u1[ls] = (a_ && pb.u_warm) ? pb.u_warm[T + tc] : 0.0;
+        }
         x00 = valid ? pb.x0[0] : 0.0; x01 = valid ? pb.x0[1] : 0.0; x02 = valid ? pb.x0[2] : 0.0; x03 = valid ? pb.x0[3] : 0.0;
     
         MPCX_UNROLL
@@ -197,21 +214,20 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             const int t = q * SPL + ls;
             act[ls] = valid && t < T;
             rate[ls] = act[ls] && t >= 1;
-            const int tc = act[ls] ? t : 0;
-            const double vb = act[ls] ? pb.xbar[2 * W + tc] : 0.0, ph = act[ls] ? pb.xbar[3 * W + tc] : 0.0;
+            const double vb = in_vb[ls], ph = in_ph[ls];
             double sn, cs;
             sincos(ph, &sn, &cs);
             A0[ls] = dt * cs; A1[ls] = -dt * vb * sn; A2[ls] = dt * sn; A3[ls] = dt * vb * cs; B3[ls] = dt * vb / P.L;
-            ended[ls] = act[ls] ? (pb.re[tc + 1] != 0) : false;
-            const double yr = act[ls] ? pb.xref[3 * W + tc + 1] : 0.0;
+            ended[ls] = in_end[ls];
+            const double yr = act[ls] ? in_yr[ls] : 0.0;
             sincos(yr, &sn, &cs);
             // perpendicular projector [[s^2, -sc], [-sc, c^2]] * w_perp + parallel projector [[c^2, cs], [cs, s^2]] * w_para
             Wxx[ls] = 2.0 * (ended[ls] ? P.Qf[0] : (sn * sn) * P.w_perp + (cs * cs) * P.w_para);
             Wxy[ls] = 2.0 * (ended[ls] ? 0.0 : (-sn * cs) * P.w_perp + (cs * sn) * P.w_para);
             Wyy[ls] = 2.0 * (ended[ls] ? P.Qf[1] : (cs * cs) * P.w_perp + (sn * sn) * P.w_para);
-            uend[ls] = act[ls] ? (pb.re[tc] != 0) : false;
-            U0[ls] = (act[ls] && pb.u_warm) ? pb.u_warm[tc] : 0.0;
-            U1[ls] = (act[ls] && pb.u_warm) ? pb.u_warm[T + tc] : 0.0;
+            uend[ls] = in_uend[ls];
+            U0[ls] = in_u0[ls];
+            U1[ls] = in_u1[ls];
             // slots beyond the horizon (and groups beyond the batch) carry all-zero data: every sweep below passes through them
             // unchanged (zero dynamics, zero weights, rows off), so the code needs no per-slot branches
             if (!act[ls]) { A0[ls] = A1[ls] = A2[ls] = A3[ls] = B3[ls] = 0.0; Wxx[ls] = Wxy[ls] = Wyy[ls] = 0.0; }
@@ -229,10 +245,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             rollout(true, F0, F1, F2, F3);
             MPCX_UNROLL
             for (int ls = 0; ls < SPL; ls++) {
-                const int t = q * SPL + ls;
-                const int tc = t + 1 <= T ? t + 1 : T;        // slots beyond the horizon read a valid column; their weights are zero
-                const double e0 = F0[ls] - pb.xref[0 * W + tc], e1 = F1[ls] - pb.xref[1 * W + tc];
-                const double e2 = F2[ls] - pb.xref[2 * W + tc], e3 = F3[ls] - pb.xref[3 * W + tc];
+                const double e0 = F0[ls] - in_r0[ls], e1 = F1[ls] - in_r1[ls];
+                const double e2 = F2[ls] - in_r2[ls], e3 = F3[ls] - in_yr[ls];
                 Q0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; Q1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; Q2[ls] = WV(ls) * e2; Q3[ls] = WP(ls) * e3;
                 Z[ls] = 0.0;
             }
@@ -248,10 +262,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         rollout(false, X0, X1, X2, X3);
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++) {
-            const int t = q * SPL + ls;
-            const int tc = t + 1 <= T ? t + 1 : T;        // slots beyond the horizon read a valid column; their weights are zero
-            X0[ls] -= pb.xref[0 * W + tc]; X1[ls] -= pb.xref[1 * W + tc]; X3[ls] -= pb.xref[3 * W + tc];
-            XRV[ls] = pb.xref[2 * W + tc];
+            X0[ls] -= in_r0[ls]; X1[ls] -= in_r1[ls]; X3[ls] -= in_yr[ls];
+            XRV[ls] = in_r2[ls];
         }
         prev_of(U1, Dprev);
         MPCX_UNROLL
