@@ -194,20 +194,45 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         // wavefront with all eight groups waiting for it; the reference window used to be read twice, each time behind a sweep)
         double in_vb[SPL], in_ph[SPL], in_yr[SPL], in_r0[SPL], in_r1[SPL], in_r2[SPL], in_u0[SPL], in_u1[SPL];
         bool in_end[SPL], in_uend[SPL];
-        MPCX_UNROLL
-        for (int ls = 0; ls < SPL; ls++) {
-            const int t = q * SPL + ls;
-            const bool a_ = valid && t < T;
-            const int tc = a_ ? t : 0;
-            const int tn = t + 1 <= T ? t + 1 : T;          // slots beyond the horizon read a valid column; their weights are zero
-            in_vb[ls] = a_ ? pb.xbar[2 * W + tc] : 0.0; in_ph[ls] = a_ ? pb.xbar[3 * W + tc] : 0.0;
-            in_end[ls] = a_ ? (pb.re[tc + 1] != 0) : false; in_uend[ls] = a_ ? (pb.re[tc] != 0) : false;
-            in_r0[ls] = valid ? pb.xref[0 * W + tn] : 0.0; in_r1[ls] = valid ? pb.xref[1 * W + tn] : 0.0;
-            in_r2[ls] = valid ? pb.xref[2 * W + tn] : 0.0; in_yr[ls] = valid ? pb.xref[3 * W + tn] : 0.0;
-            in_u0[ls] = (a_ && pb.u_warm) ? pb.u_warm[tc] : 0.0;
-            in_u1[ls] = (a_ && pb.u_warm) ? pb.u_warm[T + tc] : 0.0;
+        {
+            // loads first, unconditionally and from addresses that are valid for every lane (a group without a problem points at
+            // problem 0, slots beyond the horizon at a clamped column): a load under a lane predicate becomes its own exec-masked
+            // block with a full wait behind it, and this path had ten of those in a row.  Selects afterwards.
+            uint8_t e1[SPL], e0[SPL];
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) {
+                const int t = q * SPL + ls;
+                const int tc = t < T ? t : T - 1;
+                const int tn = t + 1 <= T ? t + 1 : T;
+                in_vb[ls] = pb.xbar[2 * W + tc]; in_ph[ls] = pb.xbar[3 * W + tc];
+                e1[ls] = pb.re[tc + 1]; e0[ls] = pb.re[tc];
+                in_r0[ls] = pb.xref[0 * W + tn]; in_r1[ls] = pb.xref[1 * W + tn];
+                in_r2[ls] = pb.xref[2 * W + tn]; in_yr[ls] = pb.xref[3 * W + tn];
+                in_u0[ls] = 0.0; in_u1[ls] = 0.0;
+            }
+            if (pb.u_warm) {            // the same for every lane of the wavefront (a launch has warm starts or it has none)
+                MPCX_UNROLL
+                for (int ls = 0; ls < SPL; ls++) {
+                    const int t = q * SPL + ls;
+                    const int tc = t < T ? t : T - 1;
+                    in_u0[ls] = pb.u_warm[tc]; in_u1[ls] = pb.u_warm[T + tc];
+                }
+            }
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) {
+                const int t = q * SPL + ls;
+                const bool a_ = valid && t < T;
+                in_vb[ls] = a_ ? in_vb[ls] : 0.0; in_ph[ls] = a_ ? in_ph[ls] : 0.0;
+                in_end[ls] = a_ && e1[ls] != 0; in_uend[ls] = a_ && e0[ls] != 0;
+                in_r0[ls] = valid ? in_r0[ls] : 0.0; in_r1[ls] = valid ? in_r1[ls] : 0.0;
+                in_r2[ls] = valid ? in_r2[ls] : 0.0; in_yr[ls] = valid ? in_yr[ls] : 0.0;
+                in_u0[ls] = a_ ? in_u0[ls] : 0.0; in_u1[ls] = a_ ? in_u1[ls] : 0.0;
+            }
         }
-        x00 = valid ? pb.x0[0] : 0.0; x01 = valid ? pb.x0[1] : 0.0; x02 = valid ? pb.x0[2] : 0.0; x03 = valid ? pb.x0[3] : 0.0;
+        {
+            const double v0 = pb.x0[0], v1 = pb.x0[1], v2 = pb.x0[2], v3 = pb.x0[3];
+            x00 = valid ? v0 : 0.0; x01 = valid ? v1 : 0.0; x02 = valid ? v2 : 0.0; x03 = valid ? v3 : 0.0;
+        }
     
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++) {
