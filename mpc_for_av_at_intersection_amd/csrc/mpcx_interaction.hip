@@ -141,18 +141,21 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int cb = 0; cb < ncand_all; cb += 8 * WAVE) {
         double ox[8], oy[8];
+        // all eight loads of the lane in flight at once, from addresses that are valid for every lane (clamped); out-of-range
+        // candidates become +inf afterwards (a load under a lane predicate is its own exec-masked block with a full wait)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int cidx = cb + u * WAVE + lane;
-            ox[u] = INFINITY; oy[u] = INFINITY;             // fails every box test
-            if (cidx < ncand_all) {
-                const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;   // o: local obstacle rank
-                int pool = ooff + o;
-                if (oskip >= 0 && pool >= oskip) pool += 1;                                    // skip self
-                const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
-                ox[u] = qq[0]; oy[u] = qq[1];
-            }
+            const int cc = cidx < ncand_all ? cidx : ncand_all - 1;
+            const int co = cc & 1, g = (cc >> 1) % steps, o = (cc >> 1) / steps;   // o: local obstacle rank
+            int pool = ooff + o;
+            if (oskip >= 0 && pool >= oskip) pool += 1;                                    // skip self
+            const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
+            ox[u] = qq[0]; oy[u] = qq[1];
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (cb + u * WAVE + lane >= ncand_all) { ox[u] = INFINITY; oy[u] = INFINITY; }       // fails every box test
         for (int sg = 0; sg < sg_limit; sg++) {             // wave-uniform
             const double b0 = s_box[sg][0], b1 = s_box[sg][1], b2 = s_box[sg][2], b3 = s_box[sg][3];
             int qn = 0;
