@@ -30,7 +30,8 @@ struct mpcx_ctx {
     bool prof_qp;               // bracket qp_kernel launches with events (mpcx_profile_qp)
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs recorded so far
     std::vector<hipEvent_t> prof_free; // recycled events
-    unsigned long long *stats = nullptr;    // run statistics of mpcx_closed_loop_run (device: agent-steps, iterations, failures, max iterations)
+    unsigned long long *stats = nullptr;    // run statistics of mpcx_closed_loop_run: per wavefront of the plant kernel (agent-steps, iterations, failures, max iterations)
+    size_t stats_slots = 0;                 // wavefront slots allocated
     const int32_t *stats_iters = nullptr;   // set by mpcx_closed_loop_run around its plant step
     void *comm = nullptr;       // ncclComm_t (mpcx_comm_init) or nullptr = single rank
     int comm_world = 1, comm_rank = 0;

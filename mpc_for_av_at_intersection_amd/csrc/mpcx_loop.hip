@@ -90,9 +90,18 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     if (rc != MPCX_OK) return rc;
     rc = mpcx_ensure_ticket(ctx);
     if (rc != MPCX_OK) return rc;
-    if (!ctx->stats) {
-        if (hipMalloc((void **)&ctx->stats, 4 * sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(ctx->stats, 0, 4 * sizeof(unsigned long long), ctx->stream) != hipSuccess)
-            return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: cannot allocate the run statistics");
+    {
+        const size_t slots = ((size_t)c->P + 63) / 64;
+        if (slots > ctx->stats_slots) {         // a larger batch: the counters so far are folded into slot 0 of the new table
+            int64_t keep[4] = {0, 0, 0, 0};
+            if (ctx->stats) { rc = mpcx_closed_loop_stats(ctx, keep, 0); if (rc != MPCX_OK) return rc; (void)hipFree(ctx->stats); ctx->stats = nullptr; ctx->stats_slots = 0; }
+            if (hipMalloc((void **)&ctx->stats, 4 * slots * sizeof(unsigned long long)) != hipSuccess ||
+                hipMemsetAsync(ctx->stats, 0, 4 * slots * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(ctx->stats, keep, sizeof keep, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: cannot allocate the run statistics");
+            ctx->stats_slots = slots;
+        }
     }
     rc = mpcx_ensure_order(ctx, (size_t)c->P);
     if (rc != MPCX_OK) return rc;
@@ -114,7 +123,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
 
     if (!ctx->stream) return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: graph replay needs a non-default stream");
     unsigned char key[sizeof ctx->loop_key];
-    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 5 * sizeof(void *) <= sizeof key,
+    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 7 * sizeof(void *) <= sizeof key,
                   "loop_key too small");
     memset(key, 0, sizeof key);
     size_t o = 0;
@@ -125,7 +134,8 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     memcpy(key + o, &ctx->tune, sizeof ctx->tune); o += sizeof ctx->tune;
     memcpy(key + o, &ctx->order, sizeof ctx->order); o += sizeof ctx->order;
     memcpy(key + o, &ctx->prev_cut, sizeof ctx->prev_cut); o += sizeof ctx->prev_cut;
-    memcpy(key + o, &ctx->qp_solver, sizeof ctx->qp_solver);       // the captured launch is the solver chosen at capture time
+    memcpy(key + o, &ctx->qp_solver, sizeof ctx->qp_solver); o += sizeof ctx->qp_solver;      // the captured launch is the solver chosen at capture time
+    memcpy(key + o, &ctx->stats, sizeof ctx->stats);
     if (!ctx->loop_exec || memcmp(key, ctx->loop_key, sizeof key) != 0) {
         if (ctx->loop_exec) {
             (void)hipStreamSynchronize(ctx->stream);
