@@ -270,7 +270,8 @@ int32_t mpcx_set_qp_solver(mpcx_ctx *ctx, int32_t which);
 
 /* ---- measurement hook: while enabled, every mpcx_qp_solve_batch launch (direct or through mpcx_closed_loop_run
  * without a graph) is bracketed by a pair of HIP events on the context's stream.  mpcx_profile_qp_read waits for
- * the recorded launches, returns their summed duration and count, and clears the record. */
+ * the recorded launches, returns their summed duration and count, and clears the record.  mpcx_closed_loop_run refuses use_graph
+ * while the hook is on (launches inside a replayed graph cannot be bracketed). */
 int32_t mpcx_profile_qp(mpcx_ctx *ctx, int32_t enable);
 int32_t mpcx_profile_qp_read(mpcx_ctx *ctx, double *total_ms, int32_t *launches);
 

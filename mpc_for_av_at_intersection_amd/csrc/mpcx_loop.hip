@@ -122,6 +122,8 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     }
 
     if (!ctx->stream) return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: graph replay needs a non-default stream");
+    if (ctx->prof_qp)       // the event pairs of mpcx_profile_qp cannot be recorded inside a replayed graph: say so instead of reporting 0 launches
+        return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: mpcx_profile_qp is on; the QP launches of a replayed graph are not bracketed by events -- run without graph or switch the hook off");
     unsigned char key[sizeof ctx->loop_key];
     static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 7 * sizeof(void *) <= sizeof key,
                   "loop_key too small");
