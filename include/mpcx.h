@@ -54,7 +54,12 @@ typedef struct {
     double R_end[2];    /* diag(10,10) (mpc.py:178) */
     double max_speed, min_speed, max_accel, max_decel, max_steer, max_dsteer /* rad/s */;
     double tol;         /* KKT tolerance (relative) */
+    int32_t model;      /* MPCX_MODEL_BICYCLE4 (lib/mpc.py) or MPCX_MODEL_JERK5 (lib/mpc_jerk.py:143-208: a fifth state integrates
+                         * the acceleration input, its initial value is free; solved by the stage-structured solver whatever the batch) */
+    int32_t reserved;
+    double jerk_weight; /* jerk_penalty_weight, mpc_jerk.py:30 (MPCX_MODEL_JERK5 only) */
 } mpcx_mpc_params;
+enum { MPCX_MODEL_BICYCLE4 = 0, MPCX_MODEL_JERK5 = 1 };
 
 mpcx_ctx *mpcx_create(int32_t device, void *hip_stream);
 void mpcx_destroy(mpcx_ctx *ctx);

@@ -11,13 +11,17 @@ _lib = None
 c_dp = C.c_void_p  # device pointers travel as raw addresses
 
 
+MODEL_BICYCLE4, MODEL_JERK5 = 0, 1      # mpcx_mpc_params.model
+
+
 class MpcParamsC(C.Structure):
     """mirror of mpcx_mpc_params (include/mpcx.h)"""
     _fields_ = [('T', C.c_int32), ('max_iter', C.c_int32), ('dt', C.c_double), ('L', C.c_double),
                 ('w_perp', C.c_double), ('w_para', C.c_double), ('R', C.c_double * 2), ('Rd', C.c_double * 2),
                 ('Q_v_yaw', C.c_double * 2), ('Qf', C.c_double * 4), ('R_end', C.c_double * 2),
                 ('max_speed', C.c_double), ('min_speed', C.c_double), ('max_accel', C.c_double),
-                ('max_decel', C.c_double), ('max_steer', C.c_double), ('max_dsteer', C.c_double), ('tol', C.c_double)]
+                ('max_decel', C.c_double), ('max_steer', C.c_double), ('max_dsteer', C.c_double), ('tol', C.c_double),
+                ('model', C.c_int32), ('reserved', C.c_int32), ('jerk_weight', C.c_double)]
 
 
 class InteractionParamsC(C.Structure):

@@ -9,6 +9,7 @@ the role of the reference's `moving_obstacles`: it is described by (x, y, v, yaw
 `run(n)` hands the whole loop to mpcx_closed_loop_run (n steps enqueued back to back, optionally as a replayed
 hipGraph); `step_staged()` drives the same kernels stage by stage through the per-stage entry points.
 """
+import dataclasses
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -214,11 +215,13 @@ def stock_routes(ctx: Context, pairs=((1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (3
 
 def synthetic_batch(ctx: Context, B: int, A: int = 8, T: int = 20, seed: int = 0, routes=None, dl=None, cd=None,
                     max_start_frac: float = 0.35, instance_slice: Optional[tuple] = None, agent_shard: Optional[tuple] = None,
-                    exchange=None):
+                    exchange=None, mpc: Optional[MpcParams] = None):
     """B instances x A agents on the stock intersection, one agent per (arm, manoeuvre)
     route, start positions staggered along the approach (seeded), v0 = 0 as in the reference's scripts.
     The workload is a function of (B, A, seed) only; a rank takes its part of it with instance_slice = (lo, hi)
-    (instance-sharded) or agent_shard = (rank, world) (agent-sharded, see IntersectionBatch)."""
+    (instance-sharded) or agent_shard = (rank, world) (agent-sharded, see IntersectionBatch).
+    `mpc` replaces the stock controller constants (its T wins over the argument; the wheelbase is always the car's), e.g.
+    MpcParams.jerk() for the controller of lib/mpc_jerk.py."""
     if routes is None:
         routes, dl, cd = stock_routes(ctx)
     rng = np.random.default_rng(seed)
@@ -229,7 +232,10 @@ def synthetic_batch(ctx: Context, B: int, A: int = 8, T: int = 20, seed: int = 0
     if instance_slice is not None:
         lo, hi = instance_slice
         route_of_agent, start = route_of_agent[lo:hi], start[lo:hi]
-    params = MpcParams(T=T, L=cd.distance_back_to_front_wheel)
+    if mpc is None:
+        params = MpcParams(T=T, L=cd.distance_back_to_front_wheel)
+    else:
+        params = dataclasses.replace(mpc, L=cd.distance_back_to_front_wheel)
     ip = InteractionParams(cutoff_margin=4 * int(np.ceil(cd.radius / dl)), L=cd.distance_back_to_front_wheel, radius=cd.radius,
                            circle_centers=np.asarray(cd.circle_centers).ravel())
     return IntersectionBatch(ctx, params, ip, routes, dl, route_of_agent, start, agent_shard=agent_shard, exchange=exchange)

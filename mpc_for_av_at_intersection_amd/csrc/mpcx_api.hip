@@ -82,6 +82,10 @@ int32_t mpcx_set_mpc_params(mpcx_ctx *ctx, const mpcx_mpc_params *p) {
     if (p->T < 1 || p->T > MPCX_T_MAX) return mpcx_fail(ctx, MPCX_E_INVALID, "horizon T=%d outside 1..%d", p->T, MPCX_T_MAX);
     if (!(p->dt > 0) || !(p->L > 0) || p->max_iter < 1 || !(p->tol > 0))
         return mpcx_fail(ctx, MPCX_E_INVALID, "dt, L, tol must be positive and max_iter >= 1");
+    if (p->model != MPCX_MODEL_BICYCLE4 && p->model != MPCX_MODEL_JERK5)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "model %d: MPCX_MODEL_BICYCLE4 (lib/mpc.py) or MPCX_MODEL_JERK5 (lib/mpc_jerk.py)", p->model);
+    if (p->model == MPCX_MODEL_JERK5 && !(p->jerk_weight >= 0.0))
+        return mpcx_fail(ctx, MPCX_E_INVALID, "jerk_weight must be >= 0");
     ctx->mpc = *p;
     ctx->have_mpc = true;
     return MPCX_OK;

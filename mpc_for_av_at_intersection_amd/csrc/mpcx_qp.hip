@@ -698,7 +698,10 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     const int T = ctx->mpc.T;
     static const int env_solver = [] { const char *e = getenv("MPCX_QP_KERNEL"); return !e ? 0 : !strcmp(e, "wave") ? 1 : !strcmp(e, "stage") ? 2 : 0; }();
     const int solver = ctx->qp_solver ? ctx->qp_solver : env_solver;
-    const bool use_stage = solver == 2 || (solver == 0 && (T > 20 || B >= MPCX_STAGE_MIN_BATCH));
+    // the five-state problem (mpcx_mpc_params.model == MPCX_MODEL_JERK5) exists in the stage-structured solver only
+    if (ctx->mpc.model == MPCX_MODEL_JERK5 && solver == 1)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: the condensed solver has no five-state (lib/mpc_jerk.py) variant; use solver 0 or 2");
+    const bool use_stage = solver == 2 || ctx->mpc.model == MPCX_MODEL_JERK5 || (solver == 0 && (T > 20 || B >= MPCX_STAGE_MIN_BATCH));
     const int32_t *order = nullptr;
     if (use_stage && (ctx->order_hint || ctx->order_now)) {      // only the stage solver draws from a queue that can be ordered
         int32_t rc = mpcx_ensure_order(ctx, (size_t)B);

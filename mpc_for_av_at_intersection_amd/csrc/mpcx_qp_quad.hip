@@ -12,9 +12,10 @@ namespace mpcx {
 typedef __attribute__((address_space(3))) double lds_double;
 
 // group geometry: LQ_ = 4 (quad_perm selectors) or 8 (row shifts + half-row mirror), both inside one DPP row of 16 lanes
-template <int LQ_, int SPL_>
+template <int LQ_, int SPL_, bool JERK_ = false>
 struct GroupCx {
     static constexpr int LQ = LQ_, SPL = SPL_;
+    static constexpr bool JERK = JERK_;       // the five-state problem of lib/mpc_jerk.py (mpcx_mpc_params.model)
     static_assert(LQ == 4 || LQ == 8, "groups of 4 or 8 lanes");
     int q, lane;
     lds_double *sh;                       // s [SPL*8][64], lam [SPL*8][64], gains [SPL*8][64]
@@ -90,7 +91,8 @@ struct QueueSrc {
 #endif
     __device__ __forceinline__ int refill_min() const { return MPCX_REFILL_GROUPS * LQ; }   // in lanes
     __device__ __forceinline__ long max_rounds() const { return ((long)a.B + 2) * (long)(a.p.max_iter + 4); }
-    __device__ __forceinline__ bool fetch(GroupCx<LQ, SPL> &cx, mpcx_mpc_params &P, mpcx_stage::Problem &pb) const {
+    template <class Cx>
+    __device__ __forceinline__ bool fetch(Cx &cx, mpcx_mpc_params &P, mpcx_stage::Problem &pb) const {
         int t = 0;
         if (cx.q == 0) t = atomicAdd(a.ticket, 1);
         t = (int)cx.gsum((double)t);                  // the other lanes contribute 0: everybody gets the leader's ticket
@@ -109,11 +111,11 @@ struct QueueSrc {
     }
 };
 
-template <int LQ, int SPL, bool TUNED>
+template <int LQ, int SPL, bool TUNED, bool JERK>
 __global__ __launch_bounds__(64, 1) void qp_quad_kernel(QpArgs a) {
     __shared__ double sh[3 * SPL * 8 * 64];
     const int lane = threadIdx.x;
-    GroupCx<LQ, SPL> cx{lane & (LQ - 1), lane, (lds_double *)sh};
+    GroupCx<LQ, SPL, JERK> cx{lane & (LQ - 1), lane, (lds_double *)sh};
     QueueSrc<LQ, SPL, TUNED> src{a};
 #ifdef MPCX_STAGE_TRACE
     if (blockIdx.x == 0) cx.trace_buf = a.kkt + 4 * (size_t)a.B;
@@ -124,21 +126,27 @@ __global__ __launch_bounds__(64, 1) void qp_quad_kernel(QpArgs a) {
 #endif
 }
 
-template <int LQ, int SPL>
+template <int LQ, int SPL, bool JERK>
 void launch_qp_group(const QpArgs &a, hipStream_t st, int n_cu) {
     const int per_wave = 64 / LQ;
     const int need = (a.B + per_wave - 1) / per_wave;
     const int resident = n_cu * 4;                      // one wavefront per SIMD
     const int grid = need < resident ? need : resident;
-    if (a.has_tune) hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, true>), dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, false>), dim3(grid), dim3(64), 0, st, a);
+    if (a.has_tune) hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, true, JERK>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, false, JERK>), dim3(grid), dim3(64), 0, st, a);
 }
 
 void launch_qp_stage(const QpArgs &a, hipStream_t st, int n_cu) {
     const int T = a.p.T;
-    if (T <= 16) launch_qp_group<8, 2>(a, st, n_cu);
-    else if (T <= 24) launch_qp_group<8, 3>(a, st, n_cu);
-    else launch_qp_group<8, 4>(a, st, n_cu);
+    if (a.p.model == MPCX_MODEL_JERK5) {
+        if (T <= 16) launch_qp_group<8, 2, true>(a, st, n_cu);
+        else if (T <= 24) launch_qp_group<8, 3, true>(a, st, n_cu);
+        else launch_qp_group<8, 4, true>(a, st, n_cu);
+        return;
+    }
+    if (T <= 16) launch_qp_group<8, 2, false>(a, st, n_cu);
+    else if (T <= 24) launch_qp_group<8, 3, false>(a, st, n_cu);
+    else launch_qp_group<8, 4, false>(a, st, n_cu);
 }
 
 }  // namespace mpcx

@@ -11,6 +11,11 @@
 // neighbour lane by DPP, and everything that is local to a stage (slacks, multipliers, residuals, step lengths)
 // runs on all lanes at once.  A wavefront therefore carries 64/LQ problems.
 //
+// Cx::JERK selects the five-state problem of lib/mpc_jerk.py:143-208 instead: the extra state x4 integrates the acceleration
+// input and feeds the speed (v' = v + dt (x4 + a), x4' = x4 + dt a, mpc_jerk.py:73-78), its initial value is a free unknown
+// (only x[:4, 0] is pinned, line 193) and the jerk term of line 190 is w (x4' - x4)^2 = w dt^2 a^2 on the stages it covers.
+// The sweeps then carry seven states (x4 last); everything local to a row is unchanged (no row involves x4).
+//
 // The code is written against a small policy class (group geometry, neighbour hand-off, group reductions, row
 // storage) so that the SAME source runs on the host with one "lane" per problem; tests/ compiles that build with
 // g++ to check the algebra against the dense CPU restatement and under the sanitizers.  It is not a product path.
@@ -48,6 +53,7 @@ struct Problem {            // one QP (pointers to that problem's rows of the ba
 template <class Cx, class Src>
 MPCX_HD void solve_queue(Cx &cx, Src &src) {
     constexpr int LQ = Cx::LQ, SPL = Cx::SPL;
+    constexpr bool JERK = Cx::JERK;
     const int q = cx.q;
     mpcx_mpc_params P = src.params();       // weights / limits may be replaced per problem by fetch(); T, dt, L never change
     Problem pb = src.first();
@@ -68,6 +74,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     bool act[SPL] = {}, rate[SPL] = {};
     double PH[SPL] = {};                                      // yaw of the linearisation point (for C_t)
     double x00 = 0.0, x01 = 0.0, x02 = 0.0, x03 = 0.0;
+    double Z0 = 0.0, jw2 = 0.0;                               // JERK: the iterate of x4_0 (uniform within a group), 2 w dt^2
     double Rda = 0.0, Rds = 0.0, wv_run = 0.0, wp_run = 0.0, wv_end = 0.0, wp_end = 0.0;
     double ra_run = 1.0, rs_run = 1.0, ra_end = 1.0, rs_end = 1.0, rmax = 0.0, hnorm = 1.0, gnorm = 1.0, tol_loose = 1e-7;
     int status = MPCX_QP_MAXITER, it = 0, loose_run = 0, max_iter = -1;
@@ -81,12 +88,14 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
 #define WP(ls) (act[ls] ? (ended[ls] ? wp_end : wp_run) : 0.0)
 #define RA_(ls) (uend[ls] ? ra_end : ra_run)
 #define RS_(ls) (uend[ls] ? rs_end : rs_run)
+#define JW_(ls) ((JERK && act[ls] && q * SPL + (ls) + 1 < T) ? jw2 : 0.0)      /* jerk term on a_t, t <= T-2 (mpc_jerk.py:188-190) */
 
 
     // ---- serial sweeps are written as "turns": lane `turn` works on its slots, then hands its carry to the neighbour
     // forward rollout of the linear model from (u0, u1): fills (X0..X3); `free` = true uses u = 0 (free response)
     auto rollout = [&](bool free_resp, double (&Y0)[SPL], double (&Y1)[SPL], double (&Y2)[SPL], double (&Y3)[SPL]) {
         double c0 = x00, c1 = x01, c2 = x02, c3 = x03;
+        double c4 = (JERK && !free_resp) ? Z0 : 0.0;
         for (int turn = 0; turn < NTURN; turn++) {
             if (q == turn) {
                 MPCX_UNROLL
@@ -97,7 +106,9 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                         // C_t = (dt v sin(phi) phi, -dt v cos(phi) phi, 0, 0) = (-a03 phi, -a13 phi, 0, 0)
                         const double n0 = c0 + A0[ls] * c2 + A1[ls] * c3 - A1[ls] * ph;
                         const double n1 = c1 + A2[ls] * c2 + A3[ls] * c3 - A3[ls] * ph;
-                        const double n2 = c2 + dt * ua, n3 = c3 + B3[ls] * us;
+                        double n2 = c2 + dt * ua;
+                        const double n3 = c3 + B3[ls] * us;
+                        if constexpr (JERK) { if (act[ls]) { n2 += dt * c4; c4 += dt * ua; } }
                         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
                     }
                     Y0[ls] = c0; Y1[ls] = c1; Y2[ls] = c2; Y3[ls] = c3;
@@ -106,13 +117,15 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             if (turn + 1 < NTURN) {
                 const double t0 = cx.prv(c0), t1 = cx.prv(c1), t2 = cx.prv(c2), t3 = cx.prv(c3);
                 c0 = t0; c1 = t1; c2 = t2; c3 = t3;      // every lane shifts: only the lane whose turn comes next uses what it got
+                if constexpr (JERK) c4 = cx.prv(c4);
             }
         }
     };
     // backward costate sweep: p_t = qx_t + A_t' p_{t+1};  out[ls] = ru[ls] + B_t' p_{t+1} (condensed gradient entries)
     auto costate = [&](const double (&Q0)[SPL], const double (&Q1)[SPL], const double (&Q2)[SPL], const double (&Q3)[SPL],
-                       const double (&G0)[SPL], const double (&G1)[SPL], double (&O0)[SPL], double (&O1)[SPL]) {
+                       const double (&G0)[SPL], const double (&G1)[SPL], double (&O0)[SPL], double (&O1)[SPL]) -> double {
         double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        double p4 = 0.0;                                      // JERK: costate of x4; what lane 0 ends with is the gradient entry of x4_0
         for (int turn = NTURN - 1; turn >= 0; turn--) {
             if (q == turn) {
                 MPCX_UNROLL
@@ -120,6 +133,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                     {
                         p0 += Q0[ls]; p1 += Q1[ls]; p2 += Q2[ls]; p3 += Q3[ls];          // gradient of x_{t+1}
                         O0[ls] = G0[ls] + dt * p2;
+                        if constexpr (JERK) { O0[ls] += dt * p4; p4 += dt * p2; }      // B' p and A' p of the fifth row / column
                         O1[ls] = G1[ls] + B3[ls] * p3;
                         const double n2 = A0[ls] * p0 + A2[ls] * p1 + p2, n3 = A1[ls] * p0 + A3[ls] * p1 + p3;
                         p2 = n2; p3 = n3;
@@ -129,8 +143,10 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             if (turn > 0) {
                 const double t0 = cx.nxt(p0), t1 = cx.nxt(p1), t2 = cx.nxt(p2), t3 = cx.nxt(p3);
                 p0 = t0; p1 = t1; p2 = t2; p3 = t3;
+                if constexpr (JERK) p4 = cx.nxt(p4);
             }
         }
+        return (JERK && q == 0) ? p4 : 0.0;
     };
 
     // neighbours of a per-slot value: previous slot (t-1) / next slot (t+1), across lanes where needed
@@ -179,7 +195,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             const double e0 = X0[ls], e1 = X1[ls], e2 = X2[ls] - XRV[ls], e3 = X3[ls];
             G0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; G1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; G2[ls] = WV(ls) * e2; G3[ls] = WP(ls) * e3;
             const bool has_next = act[ls] && (t + 1 < T);
-            double g0 = RA_(ls) * U0[ls], g1 = RS_(ls) * U1[ls];
+            double g0 = (RA_(ls) + JW_(ls)) * U0[ls], g1 = RS_(ls) * U1[ls];
             if (rate[ls]) { g0 += Rda * (U0[ls] - Up0[ls]); g1 += Rds * (U1[ls] - Up1[ls]); }
             if (has_next) { g0 -= Rda * (Un0[ls] - U0[ls]); g1 -= Rds * (Un1[ls] - U1[ls]); }
             H0[ls] = g0; H1[ls] = g1;               // zero on slots beyond the horizon (u = 0 there, no rate terms)
@@ -259,6 +275,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             PH[ls] = ph;
         }
         Rda = 2.0 * P.Rd[0]; Rds = 2.0 * P.Rd[1];
+        if constexpr (JERK) { jw2 = 2.0 * P.jerk_weight * dt * dt; Z0 = 0.0; }
         wv_run = 2.0 * P.Q_v_yaw[0]; wp_run = 2.0 * P.Q_v_yaw[1]; wv_end = 2.0 * P.Qf[2]; wp_end = 2.0 * P.Qf[3];
         ra_run = 2.0 * P.R[0]; rs_run = 2.0 * P.R[1]; ra_end = 2.0 * P.R_end[0]; rs_end = 2.0 * P.R_end[1];
         status = MPCX_QP_MAXITER; it = 0;
@@ -275,8 +292,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 Q0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; Q1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; Q2[ls] = WV(ls) * e2; Q3[ls] = WP(ls) * e3;
                 Z[ls] = 0.0;
             }
-            costate(Q0, Q1, Q2, Q3, Z, Z, O0, O1);
-            double gm = 0.0;
+            const double gz = costate(Q0, Q1, Q2, Q3, Z, Z, O0, O1);
+            double gm = fabs(gz);
             MPCX_UNROLL
             for (int ls = 0; ls < SPL; ls++) gm = fmax(gm, fmax(fabs(O0[ls]), fabs(O1[ls])));
             gnorm = fmax(1.0, cx.gmax(gm));
@@ -378,6 +395,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         cx.stamp(1);                    // [local pass A]
         // ---- dual residual: costate sweep with the multipliers
         double O0[SPL] = {}, O1[SPL] = {};
+        double rd_z = 0.0;
         {
             double Q2t[SPL], R0t[SPL], R1t[SPL];
             MPCX_UNROLL
@@ -386,7 +404,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 R0t[ls] = PH0[ls] + RL0[ls];
                 R1t[ls] = PH1[ls] + RL1[ls] + L45[ls] - L45n[ls];
             }
-            costate(PG0, PG1, Q2t, PG3, R0t, R1t, O0, O1);
+            rd_z = costate(PG0, PG1, Q2t, PG3, R0t, R1t, O0, O1);
         }
         // from here on PG / PH hold the predictor's linear terms (cost gradient + G' nu with nu = d * rp)
         MPCX_UNROLL
@@ -395,7 +413,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             PH0[ls] += RA0[ls];
             PH1[ls] += RA1[ls] + N45[ls] - N45n[ls];
         }
-        double rd_m = 0.0;
+        double rd_m = fabs(rd_z);
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++) rd_m = fmax(rd_m, fmax(fabs(O0[ls]), fabs(O1[ls])));
         const double n_rd = cx.gmax(rd_m), n_rp = cx.gmax(rp_m), n_mu = cx.gsum(mu_s) * minv;
@@ -423,6 +441,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         // pivots (I1, I2, LL) and the rate weights where it is used
         double KA0[SPL] = {}, KA1[SPL] = {}, I1[SPL] = {}, I2[SPL] = {}, LL[SPL] = {}, RHd[SPL] = {};
         bool RHon[SPL] = {};
+        double KZa[SPL] = {}, KZd[SPL] = {};       // JERK: the gain column that multiplies dx4 (registers), 1 / (cost-to-go curvature in x4_0),
+        double I66 = 1.0, DZA = 0.0;               // and the predictor's step of x4_0
         auto prev_block = [&](int ls, double &ka4, double &ka5, double &kd4, double &kd5) {
             const double ra = RHon[ls] ? Rda : 0.0, rd = RHd[ls];
             kd4 = -LL[ls] * ra * I2[ls]; ka4 = ra * I1[ls] - LL[ls] * kd4;
@@ -430,15 +450,95 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         };
         bool bad = false;
         {
-            double Pm[21], pv[6];
+            constexpr int NZ = JERK ? 7 : 6, NP = NZ * (NZ + 1) / 2;
+            double Pm[NP], pv[NZ];
             MPCX_UNROLL
-            for (int i = 0; i < 21; i++) Pm[i] = 0.0;
+            for (int i = 0; i < NP; i++) Pm[i] = 0.0;
             MPCX_UNROLL
-            for (int i = 0; i < 6; i++) pv[i] = 0.0;
+            for (int i = 0; i < NZ; i++) pv[i] = 0.0;
             for (int turn = NTURN - 1; turn >= 0; turn--) {
                 if (q == turn) {
                     MPCX_UNROLL
                     for (int ls = SPL - 1; ls >= 0; ls--) {
+                      if constexpr (JERK) {
+                        // seven states z = (dx, dy, dv, dpsi, a-, d-, dx4).  Columns of F = d z_{t+1} / d (z_t, a, delta):
+                        //   x: e0   y: e1   v: a0 e0 + a2 e1 + e2   psi: a1 e0 + a3 e1 + e3   a-, d-: 0
+                        //   x4: dt e2 + e6   a: dt e2 + e4 + dt e6   delta: b3 e3 + e5
+#define PX7(i, j) ((i) * 7 - (i) * ((i) + 1) / 2 + (j))
+                        double Pf[7][7], g[7];
+                        MPCX_UNROLL
+                        for (int i = 0; i < 7; i++)
+                            MPCX_UNROLL
+                            for (int j = i; j < 7; j++) { Pf[i][j] = Pm[PX7(i, j)]; Pf[j][i] = Pf[i][j]; }
+                        // 1. own state cost of x_{t+1} (+ speed barrier) and its gradient
+                        Pf[0][0] += Wxx[ls]; Pf[0][1] += Wxy[ls]; Pf[1][0] += Wxy[ls]; Pf[1][1] += Wyy[ls];
+                        Pf[2][2] += WV(ls) + DSv[ls]; Pf[3][3] += WP(ls);
+                        MPCX_UNROLL
+                        for (int i = 0; i < 7; i++) g[i] = pv[i];
+                        g[0] += PG0[ls]; g[1] += PG1[ls]; g[2] += PG2[ls]; g[3] += PG3[ls];
+                        const double a0 = A0[ls], a1 = A1[ls], a2 = A2[ls], a3 = A3[ls], b3 = B3[ls];
+                        // 2. G = P F, one 7-vector per column of F
+                        double Gv[7], Gp[7], Gz[7], Ga[7], Gd[7];
+                        MPCX_UNROLL
+                        for (int i = 0; i < 7; i++) {
+                            Gv[i] = a0 * Pf[i][0] + a2 * Pf[i][1] + Pf[i][2];
+                            Gp[i] = a1 * Pf[i][0] + a3 * Pf[i][1] + Pf[i][3];
+                            Gz[i] = dt * Pf[i][2] + Pf[i][6];
+                            Ga[i] = dt * (Pf[i][2] + Pf[i][6]) + Pf[i][4];
+                            Gd[i] = b3 * Pf[i][3] + Pf[i][5];
+                        }
+                        // 3. Phi = F' G through the column dot products
+                        auto Fv = [&](const double (&w)[7]) { return a0 * w[0] + a2 * w[1] + w[2]; };
+                        auto Fp = [&](const double (&w)[7]) { return a1 * w[0] + a3 * w[1] + w[3]; };
+                        auto Fz = [&](const double (&w)[7]) { return dt * w[2] + w[6]; };
+                        auto Fa = [&](const double (&w)[7]) { return dt * (w[2] + w[6]) + w[4]; };
+                        auto Fd = [&](const double (&w)[7]) { return b3 * w[3] + w[5]; };
+                        // 4. input, rate, jerk and barrier terms
+                        const double rho_a = rate[ls] ? Rda : 0.0;
+                        const double rho_d = rate[ls] ? Rds + DSr[ls] : 0.0;
+                        const double Faa = Fa(Ga) + RA_(ls) + JW_(ls) + DSa[ls] + rho_a;
+                        const double Fad = Fa(Gd);
+                        const double Fdd = Fd(Gd) + RS_(ls) + DSd[ls] + rho_d;
+                        // 5. eliminate (a, delta)
+                        bad = bad || !(Faa > 0.0);
+                        const double i1 = cx.rcp(Faa > 0.0 ? Faa : 1.0);
+                        const double l = Fad * i1;
+                        const double s2 = Fdd - l * Fad;
+                        bad = bad || !(s2 > 0.0);
+                        const double i2 = cx.rcp(s2 > 0.0 ? s2 : 1.0);
+                        I1[ls] = i1; I2[ls] = i2; LL[ls] = l; RHd[ls] = rho_d; RHon[ls] = rate[ls];
+                        const double za[7] = {Ga[0], Ga[1], Fv(Ga), Fp(Ga), -rho_a, 0.0, Fz(Ga)};
+                        const double zd[7] = {Gd[0], Gd[1], Fv(Gd), Fp(Gd), 0.0, -rho_d, Fz(Gd)};
+                        double ka[7], kd[7];
+                        MPCX_UNROLL
+                        for (int c = 0; c < 7; c++) {
+                            const double wd = zd[c] - l * za[c];
+                            kd[c] = -wd * i2;
+                            ka[c] = -za[c] * i1 - l * kd[c];
+                            if (c < 4) { cx.st_k(ls * 8 + c, ka[c]); cx.st_k(ls * 8 + 4 + c, kd[c]); }
+                        }
+                        KZa[ls] = ka[6]; KZd[ls] = kd[6];
+                        const double hu0 = Fa(g) + PH0[ls];
+                        const double hu1 = Fd(g) + PH1[ls];
+                        const double wd = hu1 - l * hu0;
+                        const double k1 = -wd * i2, k0 = -hu0 * i1 - l * k1;
+                        KA0[ls] = k0; KA1[ls] = k1;
+                        const double hz[7] = {g[0], g[1], Fv(g), Fp(g), 0.0, 0.0, Fz(g)};
+                        // 6. new cost-to-go at z_t (without x_t's own cost): Hzz + Huz' K,  hz + K' hu
+                        const double zz[28] = {Pf[0][0], Pf[0][1], Gv[0], Gp[0], 0.0, 0.0, Gz[0],
+                                               Pf[1][1], Gv[1], Gp[1], 0.0, 0.0, Gz[1],
+                                               Fv(Gv), Fv(Gp), 0.0, 0.0, Fv(Gz),
+                                               Fp(Gp), 0.0, 0.0, Fp(Gz),
+                                               rho_a, 0.0, 0.0,
+                                               rho_d, 0.0,
+                                               Fz(Gz)};
+                        MPCX_UNROLL
+                        for (int i = 0; i < 7; i++)
+                            MPCX_UNROLL
+                            for (int j = i; j < 7; j++) Pm[PX7(i, j)] = zz[PX7(i, j)] + za[i] * ka[j] + zd[i] * kd[j];
+                        MPCX_UNROLL
+                        for (int i = 0; i < 7; i++) pv[i] = hz[i] + ka[i] * hu0 + kd[i] * hu1;
+                      } else {
                         // index of (i,j), i<=j, in the packed upper triangle of a 6x6
 #define PX(i, j) ((i) * 6 - (i) * ((i) + 1) / 2 + (j))
                         // 1. own state cost of x_{t+1} (+ speed barrier) and its gradient
@@ -508,23 +608,33 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                             for (int j = i; j < 6; j++) Pm[PX(i, j)] = zz[PX(i, j)] + za[i] * ka[j] + zd[i] * kd[j];
                         MPCX_UNROLL
                         for (int i = 0; i < 6; i++) pv[i] = hz[i] + ka[i] * hu0 + kd[i] * hu1;
+                      }
                     }
                 }
                 if (turn > 0) {
                     MPCX_UNROLL
-                    for (int i = 0; i < 21; i++) Pm[i] = cx.nxt(Pm[i]);       // every lane shifts; lanes that had their turn no longer need theirs
+                    for (int i = 0; i < NP; i++) Pm[i] = cx.nxt(Pm[i]);       // every lane shifts; lanes that had their turn no longer need theirs
                     MPCX_UNROLL
-                    for (int i = 0; i < 6; i++) pv[i] = cx.nxt(pv[i]);
+                    for (int i = 0; i < NZ; i++) pv[i] = cx.nxt(pv[i]);
                 }
+            }
+            if constexpr (JERK) {
+                // lane 0 now holds the cost-to-go at t = 0, where (dx, dy, dv, dpsi) = 0 and the rate terms are off: what is left is
+                // 1/2 P66 dz^2 + pv6 dz in the free initial value of the fifth state
+                const double p66 = Pm[PX7(6, 6)];
+                bad = bad || (q == 0 && !(p66 > 0.0));
+                I66 = cx.rcp(p66 > 0.0 ? p66 : 1.0);
+                DZA = cx.gsum(q == 0 ? -pv[6] * I66 : 0.0);
             }
         }
         const bool any_bad = cx.gany(bad);
         if (running && any_bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; running = false; }
 
         // forward sweep with gains (K, kk): fills the direction (du, dx_{t+1})
-        auto forward = [&](const double (&k0)[SPL], const double (&k1)[SPL], double (&D0)[SPL], double (&D1)[SPL],
+        auto forward = [&](const double (&k0)[SPL], const double (&k1)[SPL], double dz0, double (&D0)[SPL], double (&D1)[SPL],
                            double (&E0)[SPL], double (&E1)[SPL], double (&E2)[SPL], double (&E3)[SPL]) {
-            double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double z[JERK ? 7 : 6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if constexpr (JERK) z[6] = dz0;
             for (int turn = 0; turn < NTURN; turn++) {
                 if (q == turn) {
                     double kk[SPL][8];           // this lane's gains, all in flight before the first is used
@@ -543,8 +653,11 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                                 prev_block(ls, ka4, ka5, kd4, kd5);
                                 da += ka4 * z[4] + ka5 * z[5]; dd += kd4 * z[4] + kd5 * z[5];
                             }
+                            if constexpr (JERK) { da += KZa[ls] * z[6]; dd += KZd[ls] * z[6]; }
                             const double n0 = z[0] + A0[ls] * z[2] + A1[ls] * z[3], n1 = z[1] + A2[ls] * z[2] + A3[ls] * z[3];
-                            const double n2 = z[2] + dt * da, n3 = z[3] + B3[ls] * dd;
+                            double n2 = z[2] + dt * da;
+                            const double n3 = z[3] + B3[ls] * dd;
+                            if constexpr (JERK) { if (act[ls]) { n2 += dt * z[6]; z[6] += dt * da; } }
                             z[0] = n0; z[1] = n1; z[2] = n2; z[3] = n3; z[4] = da; z[5] = dd;
                             D0[ls] = da; D1[ls] = dd;
                         }
@@ -553,7 +666,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 }
                 if (turn + 1 < NTURN) {
                     MPCX_UNROLL
-                    for (int i = 0; i < 6; i++) z[i] = cx.prv(z[i]);
+                    for (int i = 0; i < (JERK ? 7 : 6); i++) z[i] = cx.prv(z[i]);
                 }
             }
         };
@@ -575,7 +688,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         cx.stamp(3);                    // [Riccati sweep]
         // ---- predictor direction, affine step length, centring parameter
         double DA0[SPL] = {}, DA1[SPL] = {}, EA0[SPL] = {}, EA1[SPL] = {}, EA2[SPL] = {}, EA3[SPL] = {}, DAp[SPL];
-        forward(KA0, KA1, DA0, DA1, EA0, EA1, EA2, EA3);
+        forward(KA0, KA1, DZA, DA0, DA1, EA0, EA1, EA2, EA3);
         cx.stamp(4);                    // [forward sweep 1]
         prev_of(DA1, DAp);
         double al = 1.0, c1 = 0.0, c2 = 0.0;
@@ -617,6 +730,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         cx.stamp(5);                    // [local pass C]
         // ---- corrector: nu = (lam rp - alpha_aff dsa dla + sigma mu) / s ; backward vector sweep with the stored gains
         double KC0[SPL] = {}, KC1[SPL] = {};
+        double DZC = 0.0;               // JERK: the corrector's step of x4_0
         double RC[SPL][ROWS];           // rc / s of the corrector (kept in registers across the two corrector sweeps)
         {
             double C01[SPL], C23[SPL], C45[SPL], C67[SPL], C45n[SPL];
@@ -643,7 +757,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             cost_grad(CG0, CG1, CG2, CG3, CH0, CH1);
             MPCX_UNROLL
             for (int ls = 0; ls < SPL; ls++) { CG2[ls] += C67[ls]; CH0[ls] += C01[ls]; CH1[ls] += C23[ls] + C45[ls] - C45n[ls]; }
-            double pv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double pv[JERK ? 7 : 6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             for (int turn = NTURN - 1; turn >= 0; turn--) {
                 if (q == turn) {
                     double kk[SPL][8];           // this lane's gains, all in flight before the first is used
@@ -654,7 +768,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                     MPCX_UNROLL
                     for (int ls = SPL - 1; ls >= 0; ls--) {
                         const double g0 = pv[0] + CG0[ls], g1 = pv[1] + CG1[ls], g2 = pv[2] + CG2[ls], g3 = pv[3] + CG3[ls];
-                        const double hu0 = dt * g2 + pv[4] + CH0[ls];
+                        double hu0 = dt * g2 + pv[4] + CH0[ls];
+                        if constexpr (JERK) hu0 += dt * pv[6];
                         const double hu1 = B3[ls] * g3 + pv[5] + CH1[ls];
                         const double i1 = I1[ls], i2 = I2[ls], l = LL[ls];
                         const double wd = hu1 - l * hu0;
@@ -668,17 +783,19 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                             prev_block(ls, ka4, ka5, kd4, kd5);
                             pv[4] = ka4 * hu0 + kd4 * hu1; pv[5] = ka5 * hu0 + kd5 * hu1;
                         }
+                        if constexpr (JERK) pv[6] = (dt * g2 + pv[6]) + KZa[ls] * hu0 + KZd[ls] * hu1;
                     }
                 }
                 if (turn > 0) {
                     MPCX_UNROLL
-                    for (int i = 0; i < 6; i++) pv[i] = cx.nxt(pv[i]);
+                    for (int i = 0; i < (JERK ? 7 : 6); i++) pv[i] = cx.nxt(pv[i]);
                 }
             }
+            if constexpr (JERK) DZC = cx.gsum(q == 0 ? -pv[6] * I66 : 0.0);
         }
         double D0[SPL] = {}, D1[SPL] = {}, E0[SPL] = {}, E1[SPL] = {}, E2[SPL] = {}, E3[SPL] = {}, Dp[SPL];
         cx.stamp(6);                    // [local pass D + corrector vector sweep]
-        forward(KC0, KC1, D0, D1, E0, E1, E2, E3);
+        forward(KC0, KC1, DZC, D0, D1, E0, E1, E2, E3);
         cx.stamp(7);                    // [forward sweep 2]
         prev_of(D1, Dp);
         // the gains are dead from here on: their storage takes the multiplier step dl (the slack step ds is recomputed)
@@ -753,6 +870,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 U0[ls] += alpha * D0[ls]; U1[ls] += alpha * D1[ls];
                 X0[ls] += alpha * E0[ls]; X1[ls] += alpha * E1[ls]; X2[ls] += alpha * E2[ls]; X3[ls] += alpha * E3[ls];
             }
+            if constexpr (JERK) Z0 += alpha * DZC;
             it++;
         }
         cx.stamp(9);                    // [update]
@@ -762,6 +880,10 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
 #undef WP
 #undef RA_
 #undef RS_
+#undef JW_
+#ifdef PX7
+#undef PX7
+#endif
 }
 
 }  // namespace mpcx_stage

@@ -134,12 +134,15 @@ class MPC:
     def _fail_decel(self, p: MpcParams) -> float:
         return globals()['MAX_DECEL']           # module constant, read at call time (mpc.py:296)
 
+    def _max_iter(self) -> int:
+        return int(globals()['MAX_ITER'])
+
     # ------------------------------------------------------------------ one control step (mpc.py:280-299)
     def step(self, state: State) -> Tuple[float, float]:
-        if int(globals()['MAX_ITER']) != 1:
+        if self._max_iter() != 1:
             # the reference re-linearises MAX_ITER times and spaces the reference window by the previous pass's speeds (mpc.py:226-237);
             # its config has MAX_ITER = 1 and the kernels implement that one pass (window spacing from the current speed)
-            raise NotImplementedError('MAX_ITER = %r: only the single linearisation pass of the stock configuration is implemented' % (globals()['MAX_ITER'],))
+            raise NotImplementedError('MAX_ITER = %r: only the single linearisation pass of the stock configuration is implemented' % (self._max_iter(),))
         ctx = self._ctx
         p = self._make_params()
         if ctx.params != p:

@@ -66,6 +66,9 @@ class MPC(_base.MPC):
     def _fail_decel(self, p: MpcParams) -> float:
         return globals()['MAX_DECEL']           # the import-time constant, not the reloaded one (mpc_sensitivity.py:313)
 
+    def _max_iter(self) -> int:
+        return int(globals()['MAX_ITER'])
+
     def is_goal(self, state) -> bool:
         d = float(np.hypot(state.x - self.goal[0], state.y - self.goal[1]))
         near = d <= GOAL_DIS and abs(self.target_ind - len(self.cx)) < 5

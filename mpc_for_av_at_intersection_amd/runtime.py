@@ -32,6 +32,16 @@ class MpcParams:
     max_dsteer: float = float(np.deg2rad(30.0))
     max_iter: int = 60
     tol: float = 1e-10
+    model: int = _lib.MODEL_BICYCLE4     # _lib.MODEL_JERK5: the five-state problem of lib/mpc_jerk.py
+    jerk_weight: float = 1.0             # jerk_penalty_weight, mpc_jerk.py:30
+
+    @classmethod
+    def jerk(cls, **kw) -> 'MpcParams':
+        """the constants of main/lib/mpc_jerk.py:16-39: T 13, cross-track weight 10 (line 167), Rd (0.3, 1), MAX_DECEL -5"""
+        base = dict(T=13, w_perp=10.0, w_para=1.0, R=(0.01, 0.01), Rd=(0.3, 1.0), Q_v_yaw=(0.0, 0.5),
+                    Qf_base=(1.0, 1.0, 0.0, 0.5), max_accel=2.0, max_decel=-5.0, model=_lib.MODEL_JERK5, jerk_weight=1.0)
+        base.update(kw)
+        return cls(**base)
 
     def to_c(self) -> _lib.MpcParamsC:
         p = _lib.MpcParamsC()
@@ -44,6 +54,7 @@ class MpcParams:
         p.max_speed, p.min_speed = float(self.max_speed), float(self.min_speed)
         p.max_accel, p.max_decel = float(self.max_accel), float(self.max_decel)
         p.max_steer, p.max_dsteer, p.tol = float(self.max_steer), float(self.max_dsteer), float(self.tol)
+        p.model, p.reserved, p.jerk_weight = int(self.model), 0, float(self.jerk_weight)
         return p
 
     def tuning_row(self) -> np.ndarray:

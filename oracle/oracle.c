@@ -258,28 +258,19 @@ static void chol_solve(const double *Lm, int n, double *b) {
  * The reference hands the problem to ECOS (an interior-point SOCP code).  The problem is a strictly convex QP
  * (unique minimiser), restated here as a dense Mehrotra predictor-corrector primal-dual interior-point method
  * on the condensed form.  Output: x (4,T+1), u (2,T) laid out as the reference's x.value / u.value. */
-int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xref, const double *xbar,
-                     const uint8_t *re, const double *u_warm, double *x_out, double *u_out, double *lam_out,
-                     int32_t *iters, double *kkt4) {
-    int32_t T = p->T, W = T + 1, n = 2 * T, mcap = 8 * T;
-    double *H = malloc(sizeof(double) * n * n), *g = malloc(sizeof(double) * n);
-    double *G = malloc(sizeof(double) * mcap * n), *h = malloc(sizeof(double) * mcap);
-    double *S = malloc(sizeof(double) * W * 4 * n), *c = malloc(sizeof(double) * W * 4);
+/* the interior-point iteration on a dense problem  min 1/2 w'Hw + g'w  s.t. Gw <= h, from the start w (in-out).
+ * Shared by the 4-state problem (orc_qp_solve) and the 5-state jerk variant (oracle_jerk.c). */
+int32_t orc_ipm_dense(const orc_mpc_params *p, int32_t n, int32_t m, const double *H, const double *g, const double *G,
+                      const double *h, double *u, double *lam_out, int32_t *iters, double *kkt4) {
     double *M = malloc(sizeof(double) * n * n);
-    double *u = calloc(n, sizeof(double)), *du = malloc(sizeof(double) * n), *rd = malloc(sizeof(double) * n);
-    double *s = malloc(sizeof(double) * mcap), *lam = malloc(sizeof(double) * mcap), *rp = malloc(sizeof(double) * mcap);
-    double *ds = malloc(sizeof(double) * mcap), *dl = malloc(sizeof(double) * mcap), *rc = malloc(sizeof(double) * mcap);
-    double *dsa = malloc(sizeof(double) * mcap), *dla = malloc(sizeof(double) * mcap), *w = malloc(sizeof(double) * mcap);
-    int32_t m = orc_qp_build(p, x0, xref, xbar, re, H, g, G, h, S, c);
+    double *du = malloc(sizeof(double) * n), *rd = malloc(sizeof(double) * n);
+    double *s = malloc(sizeof(double) * m), *lam = malloc(sizeof(double) * m), *rp = malloc(sizeof(double) * m);
+    double *ds = malloc(sizeof(double) * m), *dl = malloc(sizeof(double) * m), *rc = malloc(sizeof(double) * m);
+    double *dsa = malloc(sizeof(double) * m), *dla = malloc(sizeof(double) * m), *w = malloc(sizeof(double) * m);
     int32_t status = ORC_MAXITER, it = 0;
     double res_d = 0, res_p = 0, mu = 0;
     const double tol_loose = p->tol > 1e-7 ? p->tol : 1e-7;
     int loose = 0, loose_run = 0;
-
-    /* x[2,0] bounds are constant rows (mpc.py:187-188 include t=0) */
-    if (x0[2] > p->max_speed + 1e-9 || x0[2] < p->min_speed - 1e-9) { status = ORC_INFEASIBLE; goto done; }
-
-    if (u_warm) for (int t = 0; t < T; t++) { u[2 * t] = u_warm[t]; u[2 * t + 1] = u_warm[T + t]; }
     for (int i = 0; i < m; i++) {
         double gi = 0; for (int k = 0; k < n; k++) gi += G[i * n + k] * u[k];
         double si = h[i] - gi;
@@ -379,26 +370,46 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
         for (int k = 0; k < n; k++) u[k] += alpha * du[k];
         for (int i = 0; i < m; i++) { s[i] += alpha * ds[i]; lam[i] += alpha * dl[i]; }
     }
-done:
     *iters = it;
     if (kkt4) {
         /* certificate on the final iterate: stationarity, primal violation, complementarity, max(lam<0) */
         double st = 0, pv = 0, cp = 0;
-        if (status != ORC_INFEASIBLE) {
-            for (int k = 0; k < n; k++) {
-                double a = g[k];
-                for (int j = 0; j < n; j++) a += H[k * n + j] * u[j];
-                for (int i = 0; i < m; i++) a += G[i * n + k] * lam[i];
-                if (fabs(a) > st) st = fabs(a);
-            }
-            for (int i = 0; i < m; i++) {
-                double a = -h[i];
-                for (int k = 0; k < n; k++) a += G[i * n + k] * u[k];
-                if (a > pv) pv = a;
-                if (fabs(a * lam[i]) > cp) cp = fabs(a * lam[i]);
-            }
+        for (int k = 0; k < n; k++) {
+            double a = g[k];
+            for (int j = 0; j < n; j++) a += H[k * n + j] * u[j];
+            for (int i = 0; i < m; i++) a += G[i * n + k] * lam[i];
+            if (fabs(a) > st) st = fabs(a);
+        }
+        for (int i = 0; i < m; i++) {
+            double a = -h[i];
+            for (int k = 0; k < n; k++) a += G[i * n + k] * u[k];
+            if (a > pv) pv = a;
+            if (fabs(a * lam[i]) > cp) cp = fabs(a * lam[i]);
         }
         kkt4[0] = st; kkt4[1] = pv; kkt4[2] = cp; kkt4[3] = mu;
+    }
+    if (lam_out) for (int i = 0; i < m; i++) lam_out[i] = lam[i];
+    free(M); free(du); free(rd); free(s); free(lam); free(rp); free(ds); free(dl); free(rc); free(dsa); free(dla); free(w);
+    return status;
+}
+
+int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xref, const double *xbar,
+                     const uint8_t *re, const double *u_warm, double *x_out, double *u_out, double *lam_out,
+                     int32_t *iters, double *kkt4) {
+    int32_t T = p->T, W = T + 1, n = 2 * T, mcap = 8 * T;
+    double *H = malloc(sizeof(double) * n * n), *g = malloc(sizeof(double) * n);
+    double *G = malloc(sizeof(double) * mcap * n), *h = malloc(sizeof(double) * mcap);
+    double *S = malloc(sizeof(double) * W * 4 * n), *c = malloc(sizeof(double) * W * 4);
+    double *u = calloc(n, sizeof(double));
+    int32_t m = orc_qp_build(p, x0, xref, xbar, re, H, g, G, h, S, c);
+    int32_t status;
+    /* x[2,0] bounds are constant rows (mpc.py:187-188 include t=0) */
+    if (x0[2] > p->max_speed + 1e-9 || x0[2] < p->min_speed - 1e-9) {
+        status = ORC_INFEASIBLE; *iters = 0;
+        if (kkt4) kkt4[0] = kkt4[1] = kkt4[2] = kkt4[3] = 0.0;
+    } else {
+        if (u_warm) for (int t = 0; t < T; t++) { u[2 * t] = u_warm[t]; u[2 * t + 1] = u_warm[T + t]; }
+        status = orc_ipm_dense(p, n, m, H, g, G, h, u, lam_out, iters, kkt4);
     }
     for (int t = 0; t < T; t++) { u_out[t] = u[2 * t]; u_out[T + t] = u[2 * t + 1]; }
     for (int t = 0; t <= T; t++)
@@ -407,9 +418,7 @@ done:
             for (int k = 0; k < n; k++) a += S[((size_t)t * 4 + i) * n + k] * u[k];
             x_out[i * W + t] = a;
         }
-    if (lam_out) for (int i = 0; i < m; i++) lam_out[i] = lam[i];
-    free(H); free(g); free(G); free(h); free(S); free(c); free(M); free(u); free(du); free(rd);
-    free(s); free(lam); free(rp); free(ds); free(dl); free(rc); free(dsa); free(dla); free(w);
+    free(H); free(g); free(G); free(h); free(S); free(c); free(u);
     return status;
 }
 

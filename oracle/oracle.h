@@ -35,6 +35,9 @@ typedef struct {
     double R_end[2];    /* diag(10,10), mpc.py:178 */
     double max_speed, min_speed, max_accel, max_decel, max_steer, max_dsteer; /* dsteer in rad/s */
     double tol;         /* KKT tolerance of the interior-point loop */
+    int32_t model;      /* 0: lib/mpc.py (4 states)   1: lib/mpc_jerk.py (5 states) */
+    int32_t reserved;
+    double jerk_weight; /* jerk_penalty_weight, mpc_jerk.py:30 (model 1 only) */
 } orc_mpc_params;
 
 /* status codes shared with the product library */
@@ -61,6 +64,16 @@ int32_t orc_qp_solve(const orc_mpc_params *p, const double *x0, const double *xr
                      const uint8_t *reaches_end, const double *u_warm /*2,T or NULL*/,
                      double *x_out /*4,(T+1)*/, double *u_out /*2,T*/, double *lam_out /*m or NULL*/,
                      int32_t *iters, double *kkt4 /*stat, prim, comp, gap*/);     /* returns status */
+
+/* the interior-point iteration itself on a dense problem (n unknowns, m rows), from the start w (in-out) */
+int32_t orc_ipm_dense(const orc_mpc_params *p, int32_t n, int32_t m, const double *H, const double *g, const double *G,
+                      const double *h, double *w, double *lam_out, int32_t *iters, double *kkt4);
+/* mpc_jerk.py:143-215 (oracle_jerk.c): unknowns [a0,d0,...,a_{T-1},d_{T-1}, z = x[4,0]], n = 2T+1; S (T+1),5,n ; c (T+1),5 */
+int32_t orc_qp_build_jerk(const orc_mpc_params *p, const double *x0, const double *xref, const double *xbar,
+                          const uint8_t *reaches_end, double *H, double *g, double *G, double *h, double *S, double *c);
+int32_t orc_qp_solve_jerk(const orc_mpc_params *p, const double *x0, const double *xref, const double *xbar,
+                          const uint8_t *reaches_end, const double *u_warm, double *x_out /*5,(T+1)*/, double *u_out /*2,T*/,
+                          double *lam_out, int32_t *iters, double *kkt4);
 
 /* motion_primitive_search.py:87-121 + obstacles.py:157-176 + linalg.py:4-54 + maths.py:4-10 */
 typedef struct {

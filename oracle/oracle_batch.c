@@ -66,8 +66,13 @@ int32_t orc_agent_step(const orc_mpc_params *p, const double *full /*n,3*/, int3
     if (target_ind < 0) { rc = -1; goto done; }
     if (u_warm) memcpy(uw, u_warm, sizeof(double) * 2 * T); else memset(uw, 0, sizeof(double) * 2 * T);
     orc_predict_motion(p, state4, uw, uw + T, xbar);
-    status = orc_qp_solve(p, state4, xref, xbar, re, uw, x_out, u_out, NULL, &iters, kkt);
-    (void)W;
+    if (p->model == 1) {            /* lib/mpc_jerk.py: five state rows come back, the reference keeps the first four (mpc_jerk.py:201-206) */
+        double x5[5 * (ORC_T_MAX + 1)];
+        status = orc_qp_solve_jerk(p, state4, xref, xbar, re, uw, x5, u_out, NULL, &iters, kkt);
+        memcpy(x_out, x5, sizeof(double) * 4 * W);
+    } else {
+        status = orc_qp_solve(p, state4, xref, xbar, re, uw, x_out, u_out, NULL, &iters, kkt);
+    }
 done:
     out6[0] = traj_idx; out6[1] = cut; out6[2] = target_ind; out6[3] = hit; out6[4] = status; out6[5] = iters;
     free(cx); free(cy); free(cyaw); free(rdl); free(tres); free(keep); free(trajs);

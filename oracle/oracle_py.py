@@ -23,7 +23,7 @@ c_bp = C.POINTER(C.c_uint8)
 
 def build(force=False):
     so = os.path.join(_HERE, 'liboracle.so')
-    src = [os.path.join(_HERE, f) for f in ('oracle.c', 'oracle_batch.c', 'oracle.h')]
+    src = [os.path.join(_HERE, f) for f in ('oracle.c', 'oracle_batch.c', 'oracle_jerk.c', 'oracle.h')]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle.so'], stdout=subprocess.DEVNULL)
     return so
@@ -41,6 +41,8 @@ def lib():
         _LIB.orc_calc_ref_trajectory.restype = C.c_int32
         _LIB.orc_qp_build.restype = C.c_int32
         _LIB.orc_qp_solve.restype = C.c_int32
+        _LIB.orc_qp_build_jerk.restype = C.c_int32
+        _LIB.orc_qp_solve_jerk.restype = C.c_int32
         _LIB.orc_resample_curve.restype = C.c_int32
         _LIB.orc_check_collision_moving_cars.restype = C.c_int32
         _LIB.orc_cutoff_idx.restype = C.c_int32
@@ -67,7 +69,8 @@ class _CParams(C.Structure):
                 ('w_perp', C.c_double), ('w_para', C.c_double), ('R', C.c_double * 2), ('Rd', C.c_double * 2),
                 ('Q_v_yaw', C.c_double * 2), ('Qf', C.c_double * 4), ('R_end', C.c_double * 2),
                 ('max_speed', C.c_double), ('min_speed', C.c_double), ('max_accel', C.c_double),
-                ('max_decel', C.c_double), ('max_steer', C.c_double), ('max_dsteer', C.c_double), ('tol', C.c_double)]
+                ('max_decel', C.c_double), ('max_steer', C.c_double), ('max_dsteer', C.c_double), ('tol', C.c_double),
+                ('model', C.c_int32), ('reserved', C.c_int32), ('jerk_weight', C.c_double)]
 
 
 @dataclass
@@ -91,6 +94,16 @@ class MpcParams:
     max_dsteer: float = float(np.deg2rad(30.0))
     max_iter: int = 60
     tol: float = 1e-10
+    model: int = 0              # 1: the five-state problem of lib/mpc_jerk.py
+    jerk_weight: float = 1.0    # mpc_jerk.py:30
+
+    @classmethod
+    def jerk(cls, **kw):
+        """the constants of main/lib/mpc_jerk.py:16-39 (T 13, cross-track weight 10, Rd (.3, 1), MAX_DECEL -5)"""
+        base = dict(T=13, w_perp=10.0, w_para=1.0, R=(0.01, 0.01), Rd=(0.3, 1.0), Q_v_yaw=(0.0, 0.5),
+                    Qf_base=(1.0, 1.0, 0.0, 0.5), max_accel=2.0, max_decel=-5.0, model=1, jerk_weight=1.0)
+        base.update(kw)
+        return cls(**base)
 
     def c(self):
         p = _CParams()
@@ -101,6 +114,7 @@ class MpcParams:
         p.R_end[:] = self.R_end
         p.max_speed, p.min_speed, p.max_accel, p.max_decel = self.max_speed, self.min_speed, self.max_accel, self.max_decel
         p.max_steer, p.max_dsteer, p.tol = self.max_steer, self.max_dsteer, self.tol
+        p.model, p.jerk_weight = self.model, self.jerk_weight
         return p
 
 
@@ -156,13 +170,14 @@ def plant_step(p: MpcParams, state4, a, delta):
 
 
 def qp_build(p: MpcParams, x0, xref, xbar, reaches_end):
-    T = p.T; n = 2 * T
-    x0 = np.ascontiguousarray(x0, np.float64); xref = np.ascontiguousarray(xref, np.float64)
-    xbar = np.ascontiguousarray(xbar, np.float64); re = np.ascontiguousarray(reaches_end, np.uint8)
+    T = p.T; n = 2 * T + (p.model == 1); nx = 5 if p.model == 1 else 4
+    x0 = np.ascontiguousarray(x0, np.float64); xref = np.ascontiguousarray(np.asarray(xref)[:4], np.float64)
+    xbar = np.ascontiguousarray(np.asarray(xbar)[:4], np.float64); re = np.ascontiguousarray(reaches_end, np.uint8)
     H = np.zeros((n, n)); g = np.zeros(n); G = np.zeros((8 * T, n)); h = np.zeros(8 * T)
-    S = np.zeros((T + 1, 4, n)); c = np.zeros((T + 1, 4))
+    S = np.zeros((T + 1, nx, n)); c = np.zeros((T + 1, nx))
     cp = p.c()
-    m = lib().orc_qp_build(C.byref(cp), _d(x0), _d(xref), _d(xbar), _b(re), _d(H), _d(g), _d(G), _d(h), _d(S), _d(c))
+    fn = lib().orc_qp_build_jerk if p.model == 1 else lib().orc_qp_build
+    m = fn(C.byref(cp), _d(x0), _d(xref), _d(xbar), _b(re), _d(H), _d(g), _d(G), _d(h), _d(S), _d(c))
     return H, g, G[:m], h[:m], S, c
 
 
@@ -177,13 +192,16 @@ class QpSolution:
 
 
 def qp_solve(p: MpcParams, x0, xref, xbar, reaches_end, u_warm=None) -> QpSolution:
+    """model 0: x is 4 x (T+1).  model 1 (lib/mpc_jerk.py): x is 5 x (T+1), row 4 the acceleration state (the reference
+    returns rows 0..3 only, mpc_jerk.py:201-206)"""
     T = p.T
-    x0 = np.ascontiguousarray(x0, np.float64); xref = np.ascontiguousarray(xref, np.float64)
-    xbar = np.ascontiguousarray(xbar, np.float64); re = np.ascontiguousarray(reaches_end, np.uint8)
-    x = np.zeros((4, T + 1)); u = np.zeros((2, T)); lam = np.zeros(8 * T); it = C.c_int32(0); kkt = np.zeros(4)
+    x0 = np.ascontiguousarray(x0, np.float64); xref = np.ascontiguousarray(np.asarray(xref)[:4], np.float64)
+    xbar = np.ascontiguousarray(np.asarray(xbar)[:4], np.float64); re = np.ascontiguousarray(reaches_end, np.uint8)
+    x = np.zeros((5 if p.model == 1 else 4, T + 1)); u = np.zeros((2, T)); lam = np.zeros(8 * T); it = C.c_int32(0); kkt = np.zeros(4)
     uw = None if u_warm is None else np.ascontiguousarray(u_warm, np.float64)
     cp = p.c()
-    st = lib().orc_qp_solve(C.byref(cp), _d(x0), _d(xref), _d(xbar), _b(re), None if uw is None else _d(uw),
+    fn = lib().orc_qp_solve_jerk if p.model == 1 else lib().orc_qp_solve
+    st = fn(C.byref(cp), _d(x0), _d(xref), _d(xbar), _b(re), None if uw is None else _d(uw),
                             _d(x), _d(u), _d(lam), C.byref(it), _d(kkt))
     return QpSolution(st, x, u, lam[:8 * T - 2], it.value, kkt)
 

@@ -1,7 +1,11 @@
 """Literal (un-condensed) restatement of the QP of main/lib/mpc.py:138-208, written against the reference source:
-variables z = [x(4,T+1) column-major by time ; u(2,T)], objective exactly as the cvxpy expression sums it, equality and
+variables z = [x(NX,T+1) column-major by time ; u(2,T)], objective exactly as the cvxpy expression sums it, equality and
 inequality rows as the constraints list.  Used only to certify oracle/GPU solutions (KKT of THIS problem) and to
-cross-check against scipy; it shares no code with oracle.c or the HIP kernel."""
+cross-check against scipy; it shares no code with oracle.c or the HIP kernel.
+
+p.model == 1 selects the problem of main/lib/mpc_jerk.py:143-208 instead: NX = 5 (the fifth state integrates the
+acceleration input, mpc_jerk.py:62-78), the jerk term of line 190, only x[:4, 0] pinned (line 193) -- the fifth state's
+initial value is a free variable of the problem."""
 import math
 
 import numpy as np
@@ -10,16 +14,21 @@ import numpy as np
 def build(p, x0, xref, xbar, reaches_end):
     """returns P, q, c0 (objective z'Pz + q'z + c0), Aeq, beq, G, h and index helpers ix(i,t), iu(j,t)"""
     T = p.T
-    nz = 4 * (T + 1) + 2 * T
+    jerk = getattr(p, 'model', 0) == 1
+    NX = 5 if jerk else 4
+    nz = NX * (T + 1) + 2 * T
+    if jerk:                        # xref / xbar of mpc_jerk.py have a fifth row of zeros (lines 91, 115)
+        xref = np.vstack([np.asarray(xref)[:4], np.zeros((1, T + 1))])
+        xbar = np.vstack([np.asarray(xbar)[:4], np.zeros((1, T + 1))])
 
     def ix(i, t):
-        return 4 * t + i
+        return NX * t + i
 
     def iu(j, t):
-        return 4 * (T + 1) + 2 * t + j
+        return NX * (T + 1) + 2 * t + j
     P = np.zeros((nz, nz)); q = np.zeros(nz); c0 = 0.0
     Aeq, beq, G, h = [], [], [], []
-    Qf = np.diag([v * T for v in p.Qf_base])
+    Qf = np.diag([v * T for v in p.Qf_base] + ([0.0] if jerk else []))
     for t in range(T + 1):
         if t > 0:
             if not reaches_end[t]:
@@ -29,22 +38,25 @@ def build(p, x0, xref, xbar, reaches_end):
                     r = xref[:2, t]
                     idx = [ix(0, t), ix(1, t)]
                     P[np.ix_(idx, idx)] += M; q[idx] += -2 * M @ r; c0 += r @ M @ r
-                Mq = np.diag(p.Q_v_yaw); r = xref[2:, t]; idx = [ix(2, t), ix(3, t)]
+                Mq = np.diag(p.Q_v_yaw); r = xref[2:4, t]; idx = [ix(2, t), ix(3, t)]
                 P[np.ix_(idx, idx)] += Mq; q[idx] += -2 * Mq @ r; c0 += r @ Mq @ r
             else:
-                r = xref[:, t]; idx = [ix(i, t) for i in range(4)]
+                r = xref[:, t]; idx = [ix(i, t) for i in range(NX)]
                 P[np.ix_(idx, idx)] += Qf; q[idx] += -2 * Qf @ r; c0 += r @ Qf @ r
         if t < T:
             v, phi, delta, dt, L = xbar[2, t], xbar[3, t], 0.0, p.dt, p.L
-            A = np.eye(4)
+            A = np.eye(NX)
             A[0, 2] = dt * math.cos(phi); A[0, 3] = -dt * v * math.sin(phi)
             A[1, 2] = dt * math.sin(phi); A[1, 3] = dt * v * math.cos(phi)
             A[3, 2] = dt * math.tan(delta) / L
-            B = np.zeros((4, 2)); B[2, 0] = dt; B[3, 1] = dt * v / (L * math.cos(delta) ** 2)
-            C = np.array([dt * v * math.sin(phi) * phi, -dt * v * math.cos(phi) * phi, 0.0, -dt * v * delta / (L * math.cos(delta) ** 2)])
-            for i in range(4):      # x[:, t+1] == A x[:, t] + B u[:, t] + C
+            B = np.zeros((NX, 2)); B[2, 0] = dt; B[3, 1] = dt * v / (L * math.cos(delta) ** 2)
+            C = np.zeros(NX)
+            C[:4] = [dt * v * math.sin(phi) * phi, -dt * v * math.cos(phi) * phi, 0.0, -dt * v * delta / (L * math.cos(delta) ** 2)]
+            if jerk:
+                A[2, 4] = dt; B[4, 0] = dt          # mpc_jerk.py:73, 78
+            for i in range(NX):     # x[:, t+1] == A x[:, t] + B u[:, t] + C
                 row = np.zeros(nz); row[ix(i, t + 1)] = 1.0
-                for j in range(4):
+                for j in range(NX):
                     row[ix(j, t)] -= A[i, j]
                 for j in range(2):
                     row[iu(j, t)] -= B[i, j]
@@ -57,10 +69,14 @@ def build(p, x0, xref, xbar, reaches_end):
             for j in range(2):
                 a, b = iu(j, t + 1), iu(j, t)
                 P[a, a] += Rd[j, j]; P[b, b] += Rd[j, j]; P[a, b] -= Rd[j, j]; P[b, a] -= Rd[j, j]
+            if jerk:                 # jerk_penalty_weight * square(x[4, t+1] - x[4, t]), mpc_jerk.py:190
+                a, b = ix(4, t + 1), ix(4, t)
+                w = p.jerk_weight
+                P[a, a] += w; P[b, b] += w; P[a, b] -= w; P[b, a] -= w
             for sgn in (1.0, -1.0):  # |u[1,t+1] - u[1,t]| <= MAX_DSTEER * dt
                 row = np.zeros(nz); row[iu(1, t + 1)] = sgn; row[iu(1, t)] = -sgn
                 G.append(row); h.append(p.max_dsteer * p.dt)
-    for i in range(4):              # x[:, 0] == x0
+    for i in range(4):              # x[:, 0] == x0  (mpc_jerk.py:193: x[:4, 0] == x0)
         row = np.zeros(nz); row[ix(i, 0)] = 1.0
         Aeq.append(row); beq.append(x0[i])
     for t in range(T + 1):

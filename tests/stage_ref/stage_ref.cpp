@@ -5,8 +5,10 @@
 #include "mpcx_qp_stage.h"
 
 namespace {
+template <bool JERK_>
 struct HostCx {
     static constexpr int LQ = 1, SPL = MPCX_T_MAX;
+    static constexpr bool JERK = JERK_;
     int q = 0;
     double s[SPL * 8], l[SPL * 8], k[SPL * 8];
     double prv(double v) const { return v; }
@@ -45,18 +47,25 @@ struct HostSrc {            // a queue of exactly one problem
     mpcx_stage::Problem first() const { return pb; }
     long max_rounds() const { return p->max_iter + 4; }
     int refill_min() const { return 1; }
-    bool fetch(HostCx &, mpcx_mpc_params &, mpcx_stage::Problem &out) { out = pb; return taken++ == 0; }
+    template <class Cx>
+    bool fetch(Cx &, mpcx_mpc_params &, mpcx_stage::Problem &out) { out = pb; return taken++ == 0; }
 };
 }  // namespace
 
 extern "C" int stage_ref_solve(const mpcx_mpc_params *p, const double *x0, const double *xref, const double *xbar,
                                const uint8_t *re, const double *u_warm, double *x_out, double *u_out, int32_t *status,
                                int32_t *iters, double *kkt) {
-    HostCx cx;
-    memset(cx.s, 0, sizeof cx.s); memset(cx.l, 0, sizeof cx.l); memset(cx.k, 0, sizeof cx.k);
     mpcx_stage::Problem pb{x0, xref, xbar, u_warm, re, x_out, u_out, kkt, status, iters};
     HostSrc src{p, pb};
-    mpcx_stage::solve_queue(cx, src);
+    if (p->model == MPCX_MODEL_JERK5) {
+        HostCx<true> cx;
+        memset(cx.s, 0, sizeof cx.s); memset(cx.l, 0, sizeof cx.l); memset(cx.k, 0, sizeof cx.k);
+        mpcx_stage::solve_queue(cx, src);
+    } else {
+        HostCx<false> cx;
+        memset(cx.s, 0, sizeof cx.s); memset(cx.l, 0, sizeof cx.l); memset(cx.k, 0, sizeof cx.k);
+        mpcx_stage::solve_queue(cx, src);
+    }
     return 0;
 }
 

@@ -22,7 +22,8 @@ def _replay_all_on_oracle(sim, before, after, threads=16, tol=2e-7, dead=None):
     over agents) from the device state `before`: integer decisions and solver status must be identical for every agent, solutions
     within tol.  Returns (worst |solution difference|, agents whose iteration count differs, failed solves)."""
     from oracle import oracle_py as orc
-    po = orc.MpcParams(T=sim.params.T, L=sim.params.L)
+    import dataclasses
+    po = orc.MpcParams(**{f.name: getattr(sim.params, f.name) for f in dataclasses.fields(orc.MpcParams)})
     tab = sim.path.cpu().numpy(); off = sim.path_off.cpu().numpy(); ln = sim.path_len.cpu().numpy()
     r = orc.agent_steps_batch(po, threads, sim.A, tab, off, ln, sim.dl, before['state'], before['applied'], before['u'],
                               before['traj_idx'], before['prev_cut'], before['target_ind'],
