@@ -348,90 +348,106 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     // problem.  `cx.any` keeps the wavefront together (cross-lane operations need every lane in the loop); the loop is
     // bounded by construction: each round either advances an iteration counter or consumes a ticket.
     const long rounds = src.max_rounds();
+    have = src.fetch(cx, P, pb);            // every group draws its first problem
+    drained = !have;
+    setup();
     for (long guard = 0; guard < rounds; guard++) {
-        const bool need = !running && !drained;
-        // hand-in / draw / set-up costs the whole wavefront a few thousand instructions: do it when at least `refill_min`
-        // groups are waiting, or when nobody is running any more
-        if (cx.count(need) >= src.refill_min() || (cx.any(need) && !cx.any(running))) {
+        double DSa[SPL], DSd[SPL], DSr[SPL], DSv[SPL];  // barrier weights d = lam/s summed over the row pairs
+        double PG0[SPL], PG1[SPL], PG2[SPL], PG3[SPL], PH0[SPL], PH1[SPL];     // predictor gradient wrt x_{t+1}, u_t
+        double n_mu = 0.0;
+        bool fresh = guard == 0;        // the group's problem entered in this round (uniform within a group)
+        // A round opens with the residuals of every group's iterate and the exit tests.  Groups that are done hand in their solution
+        // and draw the next problem RIGHT THERE, and the residual pass is repeated (for everybody: the running groups get the
+        // same numbers again), so that a new problem starts its first iteration in the round it arrives in.  (Until round 2 the
+        // refill sat in front of the residual pass, and every problem paid one whole round just to be told it had converged.)
+        MPCX_NOUNROLL
+        for (int pass = 0; pass < 2; pass++) {
+            // ---- local pass A: rows, complementarity, gradient pieces
+            prev_of(U1, Dprev);
+            double L45[SPL], N45[SPL];                    // (lam4 - lam5), (nu4 - nu5) of the predictor
+            double QL2[SPL], QA2[SPL], RL0[SPL], RL1[SPL], RA0[SPL], RA1[SPL];
+            double mu_s = 0.0, rp_m = 0.0;
+            cost_grad(PG0, PG1, PG2, PG3, PH0, PH1);
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) {
+                double lam[ROWS], nu[ROWS], dd[ROWS], sv[ROWS], lv[ROWS];
+                rows_of(ls, sv, lv);
+                MPCX_UNROLL
+                for (int r = 0; r < ROWS; r++) {
+                    const bool on = row_on(ls, r);
+                    const double s = sv[r], l = lv[r];
+                    const double is = cx.rcp(s);
+                    const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
+                    const double d = on ? l * is : 0.0;
+                    dd[r] = d;
+                    lam[r] = on ? l : 0.0; nu[r] = d * rp;
+                    mu_s += on ? s * l : 0.0;
+                    rp_m = fmax(rp_m, fabs(rp));
+                }
+                DSa[ls] = dd[0] + dd[1]; DSd[ls] = dd[2] + dd[3]; DSr[ls] = dd[4] + dd[5]; DSv[ls] = dd[6] + dd[7];
+                RL0[ls] = lam[0] - lam[1]; RL1[ls] = lam[2] - lam[3]; L45[ls] = lam[4] - lam[5]; QL2[ls] = lam[6] - lam[7];
+                RA0[ls] = nu[0] - nu[1]; RA1[ls] = nu[2] - nu[3]; N45[ls] = nu[4] - nu[5]; QA2[ls] = nu[6] - nu[7];
+            }
+            double L45n[SPL], N45n[SPL];
+            next_of(L45, L45n); next_of(N45, N45n);
+            cx.stamp(1);                    // [local pass A]
+            // ---- dual residual: costate sweep with the multipliers
+            double O0[SPL] = {}, O1[SPL] = {};
+            double rd_z = 0.0;
+            {
+                double Q2t[SPL], R0t[SPL], R1t[SPL];
+                MPCX_UNROLL
+                for (int ls = 0; ls < SPL; ls++) {
+                    Q2t[ls] = PG2[ls] + QL2[ls];
+                    R0t[ls] = PH0[ls] + RL0[ls];
+                    R1t[ls] = PH1[ls] + RL1[ls] + L45[ls] - L45n[ls];
+                }
+                rd_z = costate(PG0, PG1, Q2t, PG3, R0t, R1t, O0, O1);
+            }
+            // from here on PG / PH hold the predictor's linear terms (cost gradient + G' nu with nu = d * rp)
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) {
+                PG2[ls] += QA2[ls];
+                PH0[ls] += RA0[ls];
+                PH1[ls] += RA1[ls] + N45[ls] - N45n[ls];
+            }
+            double rd_m = fabs(rd_z);
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) rd_m = fmax(rd_m, fmax(fabs(O0[ls]), fabs(O1[ls])));
+            const double n_rd = cx.gmax(rd_m), n_rp = cx.gmax(rp_m);
+            n_mu = cx.gsum(mu_s) * minv;
+            if (running) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
+            const bool test = running && (pass == 0 || fresh);      // a group takes the exit tests once per iterate
+#ifdef MPCX_STAGE_TRACE
+            if (test) cx.trace(it, res_d, res_p, mu, trace_alpha, trace_aff, trace_sigma);
+#endif
+            cx.stamp(2);                    // [costate sweep]
+            // ---- exit tests (uniform per group)
+            if (test) {
+                if (res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol) { status = MPCX_QP_OPTIMAL; running = false; }
+            }
+            if (test && running) {
+                loose = (res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose);
+                loose_run = loose ? loose_run + 1 : 0;
+                if (loose_run >= 4) { status = MPCX_QP_OPTIMAL; running = false; }
+                else if (it == max_iter) { if (loose) status = MPCX_QP_OPTIMAL; running = false; }
+            }
+            if (pass == 1) break;
+            // hand-in / draw / set-up costs the whole wavefront a few thousand instructions: do it when at least `refill_min`
+            // groups are waiting, or when nobody is running any more
+            const bool need = !running && !drained;
+            if (!(cx.count(need) >= src.refill_min() || (cx.any(need) && !cx.any(running)))) break;
+            fresh = false;
             if (need) {                  // uniform within a group: the DPP operations inside stay inside the group
                 if (have) emit();
                 have = src.fetch(cx, P, pb);
                 drained = !have;         // the queue is empty: zero the group's data once and idle from now on
                 setup();
+                fresh = true;
             }
+            cx.stamp(0);                    // [refill / set-up]
         }
         if (!cx.any(have)) break;
-        cx.stamp(0);                    // [refill / set-up]
-        // ---- local pass A: rows, complementarity, gradient pieces
-        prev_of(U1, Dprev);
-        double DSa[SPL], DSd[SPL], DSr[SPL], DSv[SPL];  // barrier weights d = lam/s summed over the row pairs
-        double PG0[SPL], PG1[SPL], PG2[SPL], PG3[SPL], PH0[SPL], PH1[SPL];     // predictor gradient wrt x_{t+1}, u_t
-        double L45[SPL], N45[SPL];                    // (lam4 - lam5), (nu4 - nu5) of the predictor
-        double QL2[SPL], QA2[SPL], RL0[SPL], RL1[SPL], RA0[SPL], RA1[SPL];
-        double mu_s = 0.0, rp_m = 0.0;
-        cost_grad(PG0, PG1, PG2, PG3, PH0, PH1);
-        MPCX_UNROLL
-        for (int ls = 0; ls < SPL; ls++) {
-            double lam[ROWS], nu[ROWS], dd[ROWS], sv[ROWS], lv[ROWS];
-            rows_of(ls, sv, lv);
-            MPCX_UNROLL
-            for (int r = 0; r < ROWS; r++) {
-                const bool on = row_on(ls, r);
-                const double s = sv[r], l = lv[r];
-                const double is = cx.rcp(s);
-                const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
-                const double d = on ? l * is : 0.0;
-                dd[r] = d;
-                lam[r] = on ? l : 0.0; nu[r] = d * rp;
-                mu_s += on ? s * l : 0.0;
-                rp_m = fmax(rp_m, fabs(rp));
-            }
-            DSa[ls] = dd[0] + dd[1]; DSd[ls] = dd[2] + dd[3]; DSr[ls] = dd[4] + dd[5]; DSv[ls] = dd[6] + dd[7];
-            RL0[ls] = lam[0] - lam[1]; RL1[ls] = lam[2] - lam[3]; L45[ls] = lam[4] - lam[5]; QL2[ls] = lam[6] - lam[7];
-            RA0[ls] = nu[0] - nu[1]; RA1[ls] = nu[2] - nu[3]; N45[ls] = nu[4] - nu[5]; QA2[ls] = nu[6] - nu[7];
-        }
-        double L45n[SPL], N45n[SPL];
-        next_of(L45, L45n); next_of(N45, N45n);
-        cx.stamp(1);                    // [local pass A]
-        // ---- dual residual: costate sweep with the multipliers
-        double O0[SPL] = {}, O1[SPL] = {};
-        double rd_z = 0.0;
-        {
-            double Q2t[SPL], R0t[SPL], R1t[SPL];
-            MPCX_UNROLL
-            for (int ls = 0; ls < SPL; ls++) {
-                Q2t[ls] = PG2[ls] + QL2[ls];
-                R0t[ls] = PH0[ls] + RL0[ls];
-                R1t[ls] = PH1[ls] + RL1[ls] + L45[ls] - L45n[ls];
-            }
-            rd_z = costate(PG0, PG1, Q2t, PG3, R0t, R1t, O0, O1);
-        }
-        // from here on PG / PH hold the predictor's linear terms (cost gradient + G' nu with nu = d * rp)
-        MPCX_UNROLL
-        for (int ls = 0; ls < SPL; ls++) {
-            PG2[ls] += QA2[ls];
-            PH0[ls] += RA0[ls];
-            PH1[ls] += RA1[ls] + N45[ls] - N45n[ls];
-        }
-        double rd_m = fabs(rd_z);
-        MPCX_UNROLL
-        for (int ls = 0; ls < SPL; ls++) rd_m = fmax(rd_m, fmax(fabs(O0[ls]), fabs(O1[ls])));
-        const double n_rd = cx.gmax(rd_m), n_rp = cx.gmax(rp_m), n_mu = cx.gsum(mu_s) * minv;
-        if (running) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
-#ifdef MPCX_STAGE_TRACE
-        if (running) cx.trace(it, res_d, res_p, mu, trace_alpha, trace_aff, trace_sigma);
-#endif
-        cx.stamp(2);                    // [costate sweep]
-        // ---- exit tests (uniform per group)
-        if (running) {
-            if (res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol) { status = MPCX_QP_OPTIMAL; running = false; }
-        }
-        if (running) {
-            loose = (res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose);
-            loose_run = loose ? loose_run + 1 : 0;
-            if (loose_run >= 4) { status = MPCX_QP_OPTIMAL; running = false; }
-            else if (it == max_iter) { if (loose) status = MPCX_QP_OPTIMAL; running = false; }
-        }
 
         cx.fence();
         // ---- backward sweep: Riccati factorisation + predictor gains.  Carry: cost-to-go Hessian Pm (6x6 symmetric, 21
