@@ -35,10 +35,13 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_final.csv')
 
 
-def qp_flops_condensed(T: int, iters: float) -> float:
-    """algorithmic (structure-exploiting, condensed) FP64 flops of one agent-QP."""
+def qp_flops_condensed(T: int, iters: float, trial: float = 1.0) -> float:
+    """algorithmic (structure-exploiting, condensed) FP64 flops of one agent-QP.  Every QP also runs the
+    trial pass of round 2 (one factorisation of H, ONE solve, one product with G -- against two solves and four products in an
+    interior-point iteration); `iters` counts interior-point iterations only (0 for a QP the trial pass solves)."""
     n, m = 2 * T, 8 * T
-    return (16.0 / 3.0) * T ** 3 + 16.0 * T ** 2 + iters * (n ** 3 / 3.0 + 4.0 * n ** 2 + 6.0 * T ** 2 + 12.0 * m)
+    return ((16.0 / 3.0) * T ** 3 + 16.0 * T ** 2 + iters * (n ** 3 / 3.0 + 4.0 * n ** 2 + 6.0 * T ** 2 + 12.0 * m)
+            + trial * (n ** 3 / 3.0 + 2.0 * n ** 2 + 3.0 * T ** 2 + 4.0 * m))
 
 
 def qp_flops_stage(T: int, iters: float) -> float:
@@ -48,8 +51,9 @@ def qp_flops_stage(T: int, iters: float) -> float:
     gap, reciprocal, products, ratio tests), two cost-gradient evaluations 50; set-up per stage 200 (two sincos, weights, two
     rollouts).  Recomputation (rows are recomputed where needed instead of being carried) and padding are NOT counted."""
     per_iter = 300 + 2 * 52 + 60 + 16 + 512 + 50
+    per_trial = 300 + 52 + 16 + 256 + 25      # the trial pass: Riccati step, ONE forward sweep, costate sweep, two row passes, one gradient
     setup = 200
-    return T * (setup + iters * per_iter)
+    return T * (setup + iters * per_iter + per_trial)
 
 
 def pmc_executed_flops(kernel='qp_quad'):
@@ -283,6 +287,7 @@ def main():
                    'instances_total': args.batch, 'instances_per_gpu': hi - lo, 'agents': A, 'horizon': T,
                    'parallelism': 'instances sharded over %d GPU(s), no data-path collective' % world},
         'agent_qp_per_s': value * A, 'mean_ipm_iters': mean_iters, 'qp_failures': int(failures),
+        'qp_solved_by_trial_pass': float(((sim.sol['iters'] == 0) & (sim.sol['status'] == 0)).double().mean().item()),
         'roofline': {'bound': 'fp64_valu', 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved_tf / FP64_PEAK_TFLOPS,
                      'traffic': pmc_traffic_bytes() if (T == 20 and P_rank == 32768) else None,
@@ -294,7 +299,10 @@ def main():
                      'executed_pmc': None,
                      'achieved_survey_count': qp_flops_condensed(T, mean_iters) * P_rank / (qp_ms * 1e-3) / 1e12,
                      'frac_survey_count': qp_flops_condensed(T, mean_iters) * P_rank / (qp_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                     'note': 'the kernel is pure FP64 VALU (SQ_INSTS_MFMA = 0): roof = FP64 vector rate 78.6 TFLOP/s.  achieved = flops the '
+                     'note': 'mean_ipm_iters counts interior-point iterations; since round 2 every QP first runs a trial pass (unconstrained minimiser, accepted '
+                             'when it violates no row: qp_solved_by_trial_pass of the QPs end there with 0 iterations), counted in the flops as one '
+                             'factorisation + one solve.  The launch is bound by its slowest problems (max iterations x time per round), not by the mean.  '
+                             'The kernel is pure FP64 VALU (SQ_INSTS_MFMA = 0): roof = FP64 vector rate 78.6 TFLOP/s.  achieved = flops the '
                              'kernel\'s own algorithm needs (stage solver: O(T) Riccati sweeps, counted on its source) x measured mean IPM '
                              'iterations x QPs per launch / HIP-event kernel time on the launch stream.  *_survey_count = the same with '
                              'SURVEY 8(d)\'s condensed-solver count F_qp (round 1 reported that one; kept for comparison across rounds)'},
@@ -325,6 +333,23 @@ def main():
             line['steady_state_value'] = line['steady_state']['value']
         except Exception as e:                       # an extra must never take the headline line down
             line['steady_state'] = {'error': repr(e)}
+        # -------------------------------------------------------------- the same workload at four times the batch: bound by work, not by the tail
+        try:
+            if world == 1:
+                Bbig = 4 * args.batch
+                big = synthetic_batch(ctx, B=Bbig, A=A, T=T, seed=1000, routes=routes, dl=dl, cd=cd)
+                big.run(args.burn_in + args.warmup)
+                el, it, fl, ms, _ = timed(big, args.steps)
+                fq = qp_flops_condensed(T, it / (Bbig * A * args.steps))
+                line['work_bound'] = {'instances': Bbig, 'value': Bbig * args.steps / el, 'unit': 'MPC timesteps/s', 'ms_per_step': 1e3 * el / args.steps,
+                                      'kernel_ms': ms, 'mean_ipm_iters': it / (Bbig * A * args.steps), 'qp_failures': int(fl),
+                                      'frac_survey_count': fq * Bbig * A / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                      'note': 'NOT the metric\'s configuration: the same seeded workload with 4x the instances on this GPU.  At the '
+                                              'metric\'s batch a QP launch lasts as long as its slowest problem (max iterations x time per round); '
+                                              'with 16 problems per lane group instead of 4 it is bound by the work, which is what the trial pass cut'}
+                del big
+        except Exception as e:
+            line['work_bound'] = {'error': repr(e)}
         # -------------------------------------------------------------- A* expansion, config 5: 2^20-node Prius frontier, nodes sharded
         try:
             n_all = 1 << 20

@@ -52,6 +52,9 @@ int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B);             // work-queue or
 #ifndef MPCX_STEP_FRACTION
 #define MPCX_STEP_FRACTION 0.999
 #endif
+#ifndef MPCX_TRIAL_STEP
+#define MPCX_TRIAL_STEP 1      /* unconstrained trial step before the interior-point iteration: mpcx_qp_stage.h, mpcx_qp.hip (the tests' CPU checker follows the same rule) */
+#endif
 
 namespace mpcx {
 

@@ -380,6 +380,9 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     if (!feasible0) status = MPCX_QP_INFEASIBLE;
     const int max_iter = feasible0 ? P.max_iter : -1;
     const double rowm = inrow ? 1.0 : 0.0;
+    // trial step (see mpcx_qp_stage.h): the first pass runs with every multiplier taken as zero, so that M = H and the
+    // predictor direction leads to the unconstrained minimiser; if that point violates no row it is the solution (0 iterations)
+    bool trial = feasible0 && MPCX_TRIAL_STEP != 0, accepted = false;
 
     for (it = 0; it <= max_iter; it++) {
         // -------- H u from the PRISTINE Hessian (restore the band entries the previous iteration patched)
@@ -393,10 +396,11 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         double resn;
         {
             const double e2 = second_rows(u);
-            rd = m01 * (hu + g + gt_apply(m01 * l0, m01 * l1, m23 * l2, m23 * l3));
+            const double t0 = trial ? 0.0 : l0, t1 = trial ? 0.0 : l1, t2 = trial ? 0.0 : l2, t3 = trial ? 0.0 : l3;
+            rd = m01 * (hu + g + gt_apply(m01 * t0, m01 * t1, m23 * t2, m23 * t3));
             rp0 = m01 * (u + s0 - h0); rp1 = m01 * (-u + s1 - h1);
             rp2 = m23 * (e2 + s2 - h2); rp3 = m23 * (-e2 + s3 - h3);
-            mu = wave_sum_dpp(m01 * (s0 * l0 + s1 * l1) + m23 * (s2 * l2 + s3 * l3)) * minv;
+            mu = wave_sum_dpp(m01 * (s0 * t0 + s1 * t1) + m23 * (s2 * t2 + s3 * t3)) * minv;
             resn = wave_max_dpp(fmax(fabs(rd) * ign, fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))) * ihn));
         }
 #ifdef MPCX_QP_TRACE
@@ -405,27 +409,29 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 #ifdef MPCX_FIXED_ITERS
         if (it == MPCX_FIXED_ITERS) { status = MPCX_QP_OPTIMAL; break; }
 #else
-        if (resn <= P.tol && mu <= P.tol) { status = MPCX_QP_OPTIMAL; break; }
+        if (accepted) { status = MPCX_QP_OPTIMAL; break; }      // the trial point, with its residuals measured above for the report
+        if (!trial && resn <= P.tol && mu <= P.tol) { status = MPCX_QP_OPTIMAL; break; }
 #endif
         // reduced-accuracy acceptance when the iteration cannot continue (the reference accepts ECOS's OPTIMAL_INACCURATE, mpc.py:196)
-        const bool loose = resn <= tol_loose && mu <= tol_loose;
+        const bool loose = !trial && resn <= tol_loose && mu <= tol_loose;
         // stagnation exit: the stationarity residual of badly conditioned instances stalls at its rounding floor while mu keeps
         // collapsing; after 4 consecutive reduced-accuracy iterates stop before the factorisation degrades them
         loose_run = loose ? loose_run + 1 : 0;
         if (loose_run >= 4) { status = MPCX_QP_OPTIMAL; break; }
-        if (it == max_iter) { if (loose) status = MPCX_QP_OPTIMAL; break; }
+        if (!trial && it == max_iter) { if (loose) status = MPCX_QP_OPTIMAL; break; }
 
         // -------- row of M = H + G'DG: the band part (diagonal + steer tridiagonal) is written into LDS so that the row
         // reads back without per-element selects; the accel block adds dt^2 * min(S_i, S_j)
         double S;
         {
             const double is0 = frcp1(s0), is1 = frcp1(s1), is2 = frcp1(s2), is3 = frcp1(s3);
-            const double r23 = m23 * (l2 * is2 + l3 * is3);
+            const double t0 = trial ? 0.0 : l0, t1 = trial ? 0.0 : l1, t2 = trial ? 0.0 : l2, t3 = trial ? 0.0 : l3;
+            const double r23 = m23 * (t2 * is2 + t3 * is3);
             S = scan_down32(ma * r23, lane);             // accel lanes: sum_{j>=k} (d2+d3)_j ; elsewhere 0
             const double r_own = kind ? r23 : 0.0;
             const double r_prev = k0m * lane_prev(r_own);
             sh.sb[lane] = S;
-            sh.H[i_d] = h_d + (m01 * (l0 * is0 + l1 * is1) + r_own + r_prev);
+            sh.H[i_d] = h_d + (m01 * (t0 * is0 + t1 * is1) + r_own + r_prev);
             sh.H[i_hi] = h_hi - r_own;
             sh.H[i_lo] = h_lo - r_prev;
         }
@@ -502,6 +508,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #ifndef MPCX_FIXED_ITERS
+        if (bad && trial) { trial = false; it--; continue; }    // H itself did not factorise: no trial, the iteration decides
         if (bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; break; }
 #endif
 
@@ -509,14 +516,16 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         // pins make the compiler treat the inputs as new values): 80 VGPRs of the register file hold the factor.
         pin(u); pin(s0); pin(s1); pin(s2); pin(s3); pin(l0); pin(l1); pin(l2); pin(l3);
         const double is0 = frcp1(s0), is1 = frcp1(s1), is2 = frcp1(s2), is3 = frcp1(s3);
-        const double d0 = m01 * l0 * is0, d1 = m01 * l1 * is1, d2 = m23 * l2 * is2, d3 = m23 * l3 * is3;
+        const double t0 = trial ? 0.0 : l0, t1 = trial ? 0.0 : l1, t2 = trial ? 0.0 : l2, t3 = trial ? 0.0 : l3;
+        const double d0 = m01 * t0 * is0, d1 = m01 * t1 * is1, d2 = m23 * t2 * is2, d3 = m23 * t3 * is3;
+        const double e2u = second_rows(u);
         {
-            const double e2 = second_rows(u);
+            const double e2 = e2u;
             rp0 = m01 * (u + s0 - h0); rp1 = m01 * (-u + s1 - h1);
             rp2 = m23 * (e2 + s2 - h2); rp3 = m23 * (-e2 + s3 - h3);
         }
         // -------- predictor (affine scaling) direction
-        double w0 = -m01 * l0 + d0 * rp0, w1 = -m01 * l1 + d1 * rp1, w2 = -m23 * l2 + d2 * rp2, w3 = -m23 * l3 + d3 * rp3;
+        double w0 = -m01 * t0 + d0 * rp0, w1 = -m01 * t1 + d1 * rp1, w2 = -m23 * t2 + d2 * rp2, w3 = -m23 * t3 + d3 * rp3;
         double rhs = m01 * (-rd - gt_apply(w0, w1, w2, w3));
 #ifdef MPCX_SKIP_SOLVE
         double du = m01 * rhs * dinv;
@@ -524,6 +533,20 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         double du = m01 * SOLVE(rhs);
 #endif
         double f2 = second_rows(du);
+        if (trial) {
+            // the four rows of this lane at u + du
+            const double un = u + du, en = e2u + f2;
+            const bool viol = (val01 && (!(un - h0 <= 0.0) || !(-un - h1 <= 0.0))) || (val23 && (!(en - h2 <= 0.0) || !(-en - h3 <= 0.0)));
+            trial = false;
+            it--;                                   // this pass was not an iteration
+            if (__ballot(viol) == 0ull) {
+                u = un;
+                s0 = fmax(h0 - un, 1e-30); s1 = fmax(h1 + un, 1e-30); s2 = fmax(h2 - en, 1e-30); s3 = fmax(h3 + en, 1e-30);
+                l0 = l1 = l2 = l3 = 0.0;
+                accepted = true;
+            }
+            continue;
+        }
         const double dsa0 = -rp0 - m01 * du, dsa1 = -rp1 + m01 * du, dsa2 = -rp2 - f2, dsa3 = -rp3 + f2;
         const double dla0 = m01 * (-l0 - d0 * dsa0), dla1 = m01 * (-l1 - d1 * dsa1);
         const double dla2 = m23 * (-l2 - d2 * dsa2), dla3 = m23 * (-l3 - d3 * dsa3);

@@ -32,6 +32,9 @@
 #ifndef MPCX_STEP_FRACTION
 #define MPCX_STEP_FRACTION 0.999     /* fraction of the step to the boundary; see mpcx_common.h (the host build of this header has no other source) */
 #endif
+#ifndef MPCX_TRIAL_STEP
+#define MPCX_TRIAL_STEP 1            /* try the unconstrained minimiser before the interior-point iteration (see `trial` below) */
+#endif
 #define MPCX_UNROLL _Pragma("unroll")
 #define MPCX_NOUNROLL _Pragma("nounroll")
 
@@ -80,6 +83,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     int status = MPCX_QP_MAXITER, it = 0, loose_run = 0, max_iter = -1;
     double res_d = 0.0, res_p = 0.0, mu = 0.0;
     bool loose = false, running = false;    // uniform within a group; other groups of the wave may be in another state
+    // Trial step (same rule in the condensed solver and in the tests' CPU checker): a new problem's first round is run with every multiplier taken
+    // as zero -- the Riccati sweep then factorises the plain LQ problem and the predictor direction leads to its unconstrained
+    // minimiser.  If that point violates no row it is the solution (lam = 0 is its exact multiplier): the group takes the full
+    // step, reports 0 iterations and is done; about two thirds of the closed-loop problems end this way instead of spending four
+    // interior-point iterations walking lam from 1 to 1e-10.  Otherwise nothing is kept and the iteration starts as before.
+    bool trial = false, accepted = false;
 #ifdef MPCX_STAGE_TRACE
     double trace_alpha = 0.0, trace_aff = 0.0, trace_sigma = 0.0;       // dev build: per-iteration history of one problem
 #endif
@@ -322,6 +331,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         max_iter = (valid && feasible0) ? P.max_iter : -1;
         if (!feasible0) status = MPCX_QP_INFEASIBLE;
         running = valid && feasible0;
+        trial = running && MPCX_TRIAL_STEP != 0;
+        accepted = false;
     };
     // ------------------------------------------------------------------ a finished problem leaves: u, x = rollout of the linear model
     auto emit = [&]() {
@@ -375,7 +386,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 MPCX_UNROLL
                 for (int r = 0; r < ROWS; r++) {
                     const bool on = row_on(ls, r);
-                    const double s = sv[r], l = lv[r];
+                    const double s = sv[r], l = trial ? 0.0 : lv[r];
                     const double is = cx.rcp(s);
                     const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
                     const double d = on ? l * is : 0.0;
@@ -417,13 +428,14 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             const double n_rd = cx.gmax(rd_m), n_rp = cx.gmax(rp_m);
             n_mu = cx.gsum(mu_s) * minv;
             if (running) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
-            const bool test = running && (pass == 0 || fresh);      // a group takes the exit tests once per iterate
+            const bool test = running && !trial && (pass == 0 || fresh);      // a group takes the exit tests once per iterate
+            if (test && accepted) { status = MPCX_QP_OPTIMAL; running = false; }     // residuals of the accepted trial point: measured above, for the report
 #ifdef MPCX_STAGE_TRACE
             if (test) cx.trace(it, res_d, res_p, mu, trace_alpha, trace_aff, trace_sigma);
 #endif
             cx.stamp(2);                    // [costate sweep]
             // ---- exit tests (uniform per group)
-            if (test) {
+            if (test && running) {
                 if (res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol) { status = MPCX_QP_OPTIMAL; running = false; }
             }
             if (test && running) {
@@ -644,7 +656,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
         }
         const bool any_bad = cx.gany(bad);
-        if (running && any_bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; running = false; }
+        if (running && !trial && any_bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; running = false; }
 
         // forward sweep with gains (K, kk): fills the direction (du, dx_{t+1})
         auto forward = [&](const double (&k0)[SPL], const double (&k1)[SPL], double dz0, double (&D0)[SPL], double (&D1)[SPL],
@@ -708,6 +720,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         cx.stamp(4);                    // [forward sweep 1]
         prev_of(DA1, DAp);
         double al = 1.0, c1 = 0.0, c2 = 0.0;
+        bool viol = false;              // trial: a row is violated at the predictor's end point
         // per row, recomputed from (s, lam, u, x) wherever needed instead of being kept: rp = s + gap, d = lam / s
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++) {
@@ -716,11 +729,13 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             MPCX_UNROLL
             for (int r = 0; r < ROWS; r++) {
                 const bool on = row_on(ls, r);
-                const double s = sv[r], l = on ? lv[r] : 0.0;
-                const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
+                const double s = sv[r], l = (on && !trial) ? lv[r] : 0.0;
+                const double gap = row_gap(ls, r, Dprev[ls]), dir = row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]);
+                const double rp = on ? s + gap : 0.0;
                 const double d = l * cx.rcp(s);
-                const double dsa = on ? -rp - row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]) : 0.0;
+                const double dsa = on ? -rp - dir : 0.0;
                 const double dla = -l - d * dsa;
+                viol = viol || (on && !(gap + dir <= 0.0));
                 // ratio tests: any value <= the exact ratio is a valid step bound, the 0.001 margin of MPCX_STEP_FRACTION is 12 orders above rcp_fast's error
                 al = fmin(al, (on && dsa < 0.0) ? -s * cx.rcp_fast(dsa) : 1.0);
                 al = fmin(al, (on && dla < 0.0) ? -l * cx.rcp_fast(dla) : 1.0);
@@ -729,6 +744,28 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
         }
         const double alpha_aff = cx.gmin(al);
+        const bool was_trial = trial;   // the rest of this round is void for such a group (no corrector, no step, no iteration count)
+        if (trial) {
+            const bool blocked = cx.gany(viol) || any_bad;
+            if (running && !blocked) {
+                MPCX_UNROLL
+                for (int ls = 0; ls < SPL; ls++) {
+                    U0[ls] += DA0[ls]; U1[ls] += DA1[ls];
+                    X0[ls] += EA0[ls]; X1[ls] += EA1[ls]; X2[ls] += EA2[ls]; X3[ls] += EA3[ls];
+                }
+                if constexpr (JERK) Z0 += DZA;
+                // rows: the true slack (>= 0 up to rounding; floored so that lam / s stays 0) and zero multipliers
+                double Dnew[SPL];
+                prev_of(U1, Dnew);
+                MPCX_UNROLL
+                for (int ls = 0; ls < SPL; ls++)
+                    MPCX_UNROLL
+                    for (int r = 0; r < ROWS; r++)
+                        if (row_on(ls, r)) { cx.st_s(ls * ROWS + r, fmax(-row_gap(ls, r, Dnew[ls]), 1e-30)); cx.st_l(ls * ROWS + r, 0.0); }
+                accepted = true;
+            }
+            trial = false;
+        }
         // mu_aff = sum (s + a dsa)(lam + a dla) / m = mu + a c1/m + a^2 c2/m
         const double mu_aff = n_mu + alpha_aff * (cx.gsum(c1) * minv) + alpha_aff * alpha_aff * (cx.gsum(c2) * minv);
         double sigma = mu_aff / (n_mu > 0.0 ? n_mu : 1.0);
@@ -859,7 +896,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
             const double gmn = cx.gmin(pmin), gsm = cx.gsum(psum);
             const bool ok = gmn >= 1e-3 * (gsm * minv);
-            if (!cx.any(running && !ok)) break;
+            if (!cx.any(running && !was_trial && !ok)) break;
             if (!ok) alpha *= 0.7;
         }
 #ifdef MPCX_STAGE_TRACE
@@ -867,7 +904,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
 #endif
         cx.stamp(8);                    // [local pass E + safeguard]
         // ---- step
-        if (running) {
+        if (running && !was_trial) {
             {
                 double sv[SPL * ROWS], lv[SPL * ROWS], dv[SPL * ROWS];       // every load in flight before the first store
                 MPCX_UNROLL

@@ -47,6 +47,36 @@ def test_qp_vs_oracle_golden_inputs(ctx, T):
 
 
 @pytest.mark.parametrize('solver', ['condensed', 'stage'])
+@pytest.mark.parametrize('T', [13, 20])
+def test_qp_trial_step_same_decisions_as_the_oracle(ctx, solver, T):
+    """the trial pass (unconstrained minimiser, accepted when it violates no row: 0 iterations) takes the same decision in the
+    oracle and in both HIP solvers on every golden closed-loop problem, and the accepted points agree to rounding"""
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams
+    from tests.test_oracle_jerk import jerk_cases
+    orc = _orc()
+    cases = jerk_cases(T)
+    x0 = np.stack([c[0] for c in cases]); xref = np.stack([c[1] for c in cases]); xbar = np.stack([c[2] for c in cases])
+    re = np.stack([c[3] for c in cases]).astype(np.uint8)
+    warm = np.stack([np.zeros((2, T)) if c[4] is None else c[4] for c in cases])
+    ctx.set_mpc_params(MpcParams(T=T))
+    ctx.set_qp_solver(solver)
+    try:
+        out = ctx.qp_solve(ctx.f64(x0), ctx.f64(xref), ctx.f64(xbar), ctx.u8(re), ctx.f64(warm))
+        ctx.synchronize()
+    finally:
+        ctx.set_qp_solver('auto')
+    it, st, u, kkt = out['iters'].cpu().numpy(), out['status'].cpu().numpy(), out['u'].cpu().numpy(), out['kkt'].cpu().numpy()
+    po = orc.MpcParams(T=T)
+    sols = [orc.qp_solve(po, x0[k], xref[k], xbar[k], re[k], warm[k]) for k in range(len(cases))]
+    oit = np.array([s.iters for s in sols])
+    assert (st == 0).all() and np.array_equal(it == 0, oit == 0) and (oit == 0).sum() >= 30
+    assert (np.abs(it - oit) <= 1).all()
+    z = oit == 0
+    assert max(np.abs(u[k] - sols[k].u).max() for k in np.nonzero(z)[0]) < 1e-10
+    assert kkt[z, 1].max() < 1e-12 and kkt[z, 2].max() == 0.0          # primal residual / complementarity of an accepted trial point
+
+
+@pytest.mark.parametrize('solver', ['condensed', 'stage'])
 def test_qp_vs_exact_active_set_solution(ctx, solver):
     """both HIP solvers against the EXACT minimiser of the literal problem of mpc.py:138-208 (tests/qp_literal.exact_solution:
     active-set KKT solve in numpy, no code shared with oracle.c or the kernels), all 60 golden problems, T = 20"""

@@ -88,3 +88,26 @@ def test_status_codes_and_warm_start():
     assert orc.qp_solve(p, st, *args).status == 2
     p1 = orc.MpcParams(T=20, max_iter=2)
     assert orc.qp_solve(p1, g['T20/state'][4], *args).status == 1
+
+
+def test_trial_step_returns_the_unconstrained_minimiser():
+    """round 2: before the interior-point iteration the oracle (and both HIP solvers) try w = u0 - H^-1 (H u0 + g); where no row is
+    violated that point is returned with 0 iterations.  Here: on the golden closed-loop problems it equals numpy's solve of the
+    dense system, the exact active-set solution of the literal problem has no active row there, and problems with active rows
+    never take the shortcut."""
+    from tests.test_oracle_jerk import jerk_cases
+    p = orc.MpcParams(T=13)
+    n0 = 0
+    for x0, xref, xbar, re, warm in jerk_cases(13):
+        sol = orc.qp_solve(p, x0, xref, xbar, re, warm)
+        Hm, g, G, h, S, c = orc.qp_build(p, x0, xref, xbar, re)
+        w = np.linalg.solve(Hm, -g)
+        free = bool((G @ w - h <= 0).all())
+        assert (sol.iters == 0) == free
+        if free:
+            n0 += 1
+            u = np.empty(2 * p.T); u[0::2] = sol.u[0]; u[1::2] = sol.u[1]
+            assert np.abs(u - w).max() < 1e-11 and (sol.lam == 0).all()
+            ex = QL.exact_solution(p, x0, xref, xbar, re, QL.pack(p, sol.x, sol.u))
+            assert len(ex['active']) == 0 and np.abs(ex['z'] - QL.pack(p, sol.x, sol.u)).max() < 1e-10
+    assert n0 >= 30, n0
