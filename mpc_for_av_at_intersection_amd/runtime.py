@@ -2,6 +2,7 @@
 computation happens in libmpcx.so's HIP kernels.  No CPU fallback exists: constructing a Context without a
 GPU or without the built library raises."""
 import ctypes as C
+import functools
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
 
@@ -94,8 +95,28 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _ordered(fn):
+    """Every launch goes to the CONTEXT's stream.  When that is not torch's current stream (a Context created on a stream of its
+    own while the caller's tensors are produced and consumed on another), the call is ordered on both sides: the context's stream
+    first waits for what the current stream has queued (the inputs), and the current stream afterwards waits for the launch (the
+    outputs; that also keeps the caching allocator from handing a buffer back while a kernel still uses it).  Two event
+    operations, and nothing at all in the default case of one shared stream."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        cur = torch.cuda.current_stream(self.device)
+        if cur == self.stream:
+            return fn(self, *a, **k)
+        self.stream.wait_stream(cur)
+        try:
+            return fn(self, *a, **k)
+        finally:
+            cur.wait_stream(self.stream)
+    return wrapped
+
+
 class Context:
-    """One mpcx_ctx bound to a torch device and (by default) torch's current stream on it."""
+    """One mpcx_ctx bound to a torch device and (by default) torch's current stream on it.  A Context on a stream of its own may be
+    used from any current stream: see _ordered."""
 
     def __init__(self, device: int = 0, stream: Optional[torch.cuda.Stream] = None):
         self.lib = _lib.load()
@@ -147,6 +168,7 @@ class Context:
         self._chk(self.lib.mpcx_set_mpc_params(self._ctx, C.byref(cp)))
         self.params = p
 
+    @_ordered
     def qp_solve(self, x0, xref, xbar, reaches_end, u_warm=None, out=None):
         """mpcx_qp_solve_batch. Returns dict(x (B,4,T+1), u (B,2,T), status, iters, kkt)."""
         T = self.params.T
@@ -167,6 +189,7 @@ class Context:
                                                _ptr(out['iters']), _ptr(out['kkt'])))
         return out
 
+    @_ordered
     def prepare(self, state, u_warm, path, path_off, path_len, dl, target_ind, out=None, path_v=None):
         """mpcx_mpc_prepare_batch. target_ind is updated in place. Returns dict(xref, reaches_end, xbar)."""
         T = self.params.T
@@ -186,6 +209,7 @@ class Context:
                                                   _ptr(out['xref']), _ptr(out['reaches_end']), _ptr(out['xbar'])))
         return out
 
+    @_ordered
     def plant_step(self, state, u, status, applied):
         B = state.shape[0]
         self._want(state, torch.float64, (B, 4), 'state'); self._want(applied, torch.float64, (B, 2), 'applied')
@@ -194,6 +218,7 @@ class Context:
     def search_model(self, templates, last_pose, edge_cost, hp, hp_off):
         return SearchModel(self, templates, last_pose, edge_cost, hp, hp_off)
 
+    @_ordered
     def expand(self, model: 'SearchModel', nodes, out=None, nodes_cs=None):
         """mpcx_expand_batch: nodes (n,3) -> dict(nbr (n,P,3), cost (n,P), collide (n,P) uint8).
         nodes_cs (n,2): optional host-computed cos/sin of the headings (bit-exact replay of the reference's search)."""
@@ -210,6 +235,7 @@ class Context:
                                              _ptr(out['collide'])))
         return out
 
+    @_ordered
     def expand_multi(self, models, seg_off, nodes, nodes_cs=None):
         """mpcx_expand_multi_batch: nodes (n,3) grouped by search, seg_off = n_seg+1 offsets (host ints), models = one
         SearchModel per segment.  Returns dict(nbr (n,P,3), cost (n,P), collide (n,P)) laid out like separate expand() calls."""
@@ -227,6 +253,7 @@ class Context:
                                                    _ptr(out['cost']), _ptr(out['collide'])))
         return out
 
+    @_ordered
     def interaction(self, ip: InteractionParams, state, path, path_cs, path_off, path_len, prev_cut_len,
                     obs6, obs_off, obs_cnt, obs_skip, traj_idx, out=None):
         """mpcx_interaction_batch. traj_idx updated in place. Returns dict(hit_idx, hit_xy, cut_len)."""
@@ -248,6 +275,7 @@ class Context:
                                                   _ptr(out['hit_idx']), _ptr(out['hit_xy']), _ptr(out['cut_len'])))
         return out
 
+    @_ordered
     def moving_collision(self, ip: InteractionParams, ego, ego_cs, ego_off, ego_len, path, path_cs, path_off, path_len,
                          obs, obs_cs, obs_off, obs_cnt, out=None):
         """mpcx_moving_collision_batch (explicit trajectories). Returns dict(hit_idx, hit_xy)."""
@@ -263,6 +291,7 @@ class Context:
                                                        _ptr(out['hit_idx']), _ptr(out['hit_xy'])))
         return out
 
+    @_ordered
     def transform(self, nodes, pts_off, pts_cnt, pts, max_pts):
         """mpcx_transform_batch -> (n, max_pts, 3)"""
         n = nodes.shape[0]
@@ -270,23 +299,27 @@ class Context:
         self._chk(self.lib.mpcx_transform_batch(self._ctx, n, int(max_pts), _ptr(nodes), _ptr(pts_off), _ptr(pts_cnt), _ptr(pts), _ptr(out)))
         return out
 
+    @_ordered
     def cutoff_index(self, pts, off, ln, xy, radius=0.001):
         Pn = off.shape[0]
         out = torch.empty(Pn, dtype=torch.int32, device=self.device)
         self._chk(self.lib.mpcx_cutoff_index_batch(self._ctx, Pn, _ptr(pts), _ptr(off), _ptr(ln), _ptr(xy), C.c_double(radius), _ptr(out)))
         return out
 
+    @_ordered
     def predict_obstacles(self, obs6, steps, dt, L):
         n = obs6.shape[0]
         out = torch.empty((n, steps, 3), dtype=torch.float64, device=self.device)
         self._chk(self.lib.mpcx_predict_obstacles_batch(self._ctx, n, int(steps), C.c_double(dt), C.c_double(L), _ptr(obs6), _ptr(out)))
         return out
 
+    @_ordered
     def closed_loop_run(self, ip: InteractionParams, desc: '_lib.ClosedLoopC', n_steps: int, graph: bool = False):
         """mpcx_closed_loop_run: n_steps of the scenario loop body on the buffers `desc` names, no host work between."""
         cip = ip.to_c()
         self._chk(self.lib.mpcx_closed_loop_run(self._ctx, C.byref(cip), C.byref(desc), int(n_steps), 1 if graph else 0))
 
+    @_ordered
     def closed_loop_stats(self, reset: bool = True):
         """mpcx_closed_loop_stats: dict(agent_steps, iterations, failures, max_iterations) accumulated on the device by
         closed_loop_run since the last reset (synchronises)"""
@@ -294,6 +327,7 @@ class Context:
         self._chk(self.lib.mpcx_closed_loop_stats(self._ctx, out, 1 if reset else 0))
         return dict(agent_steps=int(out[0]), iterations=int(out[1]), failures=int(out[2]), max_iterations=int(out[3]))
 
+    @_ordered
     def set_instance_tuning(self, rows: Optional[torch.Tensor]):
         """mpcx_set_instance_tuning: rows (B,16) float64 device tensor (MpcParams.tuning_row per problem) or None to clear.
         The tensor is kept alive by the context while set."""
@@ -304,6 +338,7 @@ class Context:
             self._chk(self.lib.mpcx_set_instance_tuning(self._ctx, _ptr(rows), int(rows.shape[0])))
         self._tuning = rows
 
+    @_ordered
     def set_qp_order_hint(self, prev_iters: Optional[torch.Tensor], ref_now: Optional[torch.Tensor] = None,
                           ref_prev: Optional[torch.Tensor] = None):
         """mpcx_qp_set_order_hint: int32 device tensors -- the previous solve's iteration counts (may be the `iters` output) and,
@@ -322,6 +357,7 @@ class Context:
         """bracket every qp_kernel launch with HIP events on the context's stream (mpcx_profile_qp)"""
         self._chk(self.lib.mpcx_profile_qp(self._ctx, 1 if enable else 0))
 
+    @_ordered
     def profile_qp_read(self):
         """(summed milliseconds, launches) of the bracketed qp_kernel launches since the last read"""
         ms, n = C.c_double(0.0), C.c_int32(0)
@@ -346,6 +382,7 @@ class Context:
         self._chk(self.lib.mpcx_comm_destroy(self._ctx))
         self.comm_world, self.comm_rank = 1, 0
 
+    @_ordered
     def allgather_states(self, layout: int, local: torch.Tensor, out: torch.Tensor):
         """mpcx_allgather_states: local (n_inst, agents_local, 6) -> out, laid out as include/mpcx.h describes for `layout`"""
         n_inst, a_loc = int(local.shape[0]), int(local.shape[1])

@@ -136,3 +136,34 @@ def test_closed_loop_run_statistics():
     s = ctx.closed_loop_stats(reset=False)
     assert s['agent_steps'] == 3 * sim.P and ctx.closed_loop_stats()['agent_steps'] == 3 * sim.P
     assert ctx.closed_loop_stats()['agent_steps'] == 0
+
+
+def test_context_on_a_stream_of_its_own():
+    """A Context bound to its own HIP stream, used while torch's CURRENT stream is another one (inputs uploaded and outputs read on
+    the default stream): every call is ordered against the current stream on both sides (runtime._ordered), so the results equal
+    the single-stream run bit for bit -- route planning (hundreds of small launches with host round trips), a batched solve and a
+    coupled closed loop."""
+    from mpc_for_av_at_intersection_amd.batch import stock_routes, synthetic_batch
+    from mpc_for_av_at_intersection_amd.runtime import Context, MpcParams
+    ref = Context(0)
+    own = Context(0, stream=torch.cuda.Stream())
+    assert own.stream != torch.cuda.current_stream()
+    try:
+        out = []
+        for c in (ref, own):
+            routes, dl, cd = stock_routes(c)
+            sim = synthetic_batch(c, B=96, A=8, T=20, seed=2, routes=routes, dl=dl, cd=cd)
+            sim.run(6)
+            sim.step()
+            snap = sim.snapshot()
+            g = H.gold('mpc_pre.npz')
+            c.set_mpc_params(MpcParams(T=20))
+            sol = c.qp_solve(c.f64(g['T20/state']), c.f64(g['T20/xref']), c.f64(g['T20/xbar']), c.u8(g['T20/reaches_end']))
+            out.append((routes, snap, sol['u'].cpu().numpy(), sol['iters'].cpu().numpy()))
+        (r0, s0, u0, i0), (r1, s1, u1, i1) = out
+        assert len(r0) == len(r1) and all(np.array_equal(a, b) for a, b in zip(r0, r1))
+        for k in s0:
+            assert np.array_equal(s0[k], s1[k]), k
+        assert np.array_equal(u0, u1) and np.array_equal(i0, i1)
+    finally:
+        own.close(); ref.close()
