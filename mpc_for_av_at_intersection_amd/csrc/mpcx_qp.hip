@@ -43,11 +43,12 @@
 // automatic choice: the stage-structured solver wins on throughput (8 problems per wavefront, O(T) work) once the batch fills
 // the chip, the condensed solver on latency (one problem per wavefront: 0.08-0.26 ms per launch up to ~1000 problems against a
 // 0.37-0.78 ms floor); measured crossover on the closed-loop benchmark workload (warm starts, mean 6.2 iterations with a tail to ~20: a small batch is bound by its
-// SLOWEST problem, 37 us per iteration here against ~20 us in the condensed kernel): ~6144 problems at T = 20 (round 2: 4096 problems 0.65 vs 0.52 ms,
-// 6144 0.68 vs 0.69, 8192 0.69 vs 0.87).  Beyond T = 20 the condensed kernel
-// spills and is never competitive.
+// SLOWEST problem, 41 us per iteration here against ~18 us in the condensed kernel): ~10000 problems at T = 20.  With the trial pass
+// (three quarters of the problems need one pass only) the condensed kernel's work fell more than the stage solver's tail; launch
+// times condensed / stage: 4096 problems 0.40 / 0.64 ms, 8192 0.61 / 0.68, 12288 0.82 / 0.69, 16384 1.04 / 0.71, 24576 1.45 / 0.76.
+// Beyond T = 20 the condensed kernel spills and is never competitive.
 #ifndef MPCX_STAGE_MIN_BATCH
-#define MPCX_STAGE_MIN_BATCH 6144
+#define MPCX_STAGE_MIN_BATCH 10240
 #endif
 
 namespace mpcx {
