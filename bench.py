@@ -84,7 +84,7 @@ def qp_launch_bytes(T: int, P: int) -> float:
     return P * (32 + 2 * 32 * (T + 1) + (T + 1) + 16 * T + 32 * (T + 1) + 16 * T + 40)
 
 
-def pmc_traffic_bytes(kernel='qp_'):
+def pmc_traffic_bytes(kernel='mpcx::qp_quad_kernel'):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (bench.py cannot run the profiler on
     itself): 2 x FETCH_SIZE (gfx950 under-reports reads by 2x, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE, KiB -> bytes."""
     if not os.path.exists(PMC_FILE):
@@ -92,7 +92,7 @@ def pmc_traffic_bytes(kernel='qp_'):
     vals = {}
     for line in open(PMC_FILE):
         parts = line.strip().rsplit(',', 2)          # kernel names contain commas (template arguments)
-        if len(parts) == 3 and kernel in parts[0] and parts[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
+        if len(parts) == 3 and parts[0].startswith(kernel) and parts[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
             vals[parts[1]] = float(parts[2])
     if len(vals) != 2:
         return None
@@ -193,7 +193,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mpc_for_av_at_intersection_amd.batch import prius_frontier, stock_routes, synthetic_batch
-    from mpc_for_av_at_intersection_amd.runtime import Context
+    from mpc_for_av_at_intersection_amd.runtime import Context, MpcParams
     from mpc_for_av_at_intersection_amd import sharding
     ctx = Context(local)
     routes, dl, cd = stock_routes(ctx)
@@ -250,6 +250,7 @@ def main():
         it_loc = float(iters_sum.item()) if staged else float(st['iterations'])
         fl_loc = float(fail_sum.item()) if staged else float(st['failures'])
         it = sum_over_ranks(it_loc); fl = sum_over_ranks(fl_loc)
+        timed.max_iterations = int(max_over_ranks(float(st['max_iterations'])))      # of the region just timed
         return max_over_ranks(el), it, fl, qp_ms / max(qp_n, 1), qp_n
 
     # ------------------------------------------------------------------ headline: strong scaling over instances
@@ -267,6 +268,7 @@ def main():
     snap = sim.snapshot() if (rank == 0 and not args.no_cpu) else None
 
     elapsed, it_total, failures, qp_ms, qp_launches = timed(sim, args.steps)
+    max_iters = timed.max_iterations
     P_total = args.batch * A
     P_rank = sim.P
     mean_iters = it_total / (P_total * args.steps)
@@ -286,7 +288,7 @@ def main():
                                % (A, args.batch, T, args.burn_in),
                    'instances_total': args.batch, 'instances_per_gpu': hi - lo, 'agents': A, 'horizon': T,
                    'parallelism': 'instances sharded over %d GPU(s), no data-path collective' % world},
-        'agent_qp_per_s': value * A, 'mean_ipm_iters': mean_iters, 'qp_failures': int(failures),
+        'agent_qp_per_s': value * A, 'mean_ipm_iters': mean_iters, 'max_ipm_iters': max_iters, 'qp_failures': int(failures),
         'qp_solved_by_trial_pass': float(((sim.sol['iters'] == 0) & (sim.sol['status'] == 0)).double().mean().item()),
         'roofline': {'bound': 'fp64_valu', 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved_tf / FP64_PEAK_TFLOPS,
@@ -350,6 +352,21 @@ def main():
                 del big
         except Exception as e:
             line['work_bound'] = {'error': repr(e)}
+        # -------------------------------------------------------------- the five-state controller of lib/mpc_jerk.py on the same workload
+        try:
+            if world == 1:
+                jp = MpcParams.jerk()
+                js = synthetic_batch(ctx, B=args.batch, A=A, seed=1000, routes=routes, dl=dl, cd=cd, mpc=jp)
+                js.run(args.burn_in + args.warmup)
+                el, it, fl, ms, _ = timed(js, args.steps)
+                line['mpc_jerk'] = {'value': args.batch * args.steps / el, 'unit': 'MPC timesteps/s', 'horizon': jp.T, 'ms_per_step': 1e3 * el / args.steps,
+                                    'kernel_ms': ms, 'mean_ipm_iters': it / (P_total * args.steps), 'max_ipm_iters': timed.max_iterations,
+                                    'qp_failures': int(fl),
+                                    'note': 'NOT the metric: the same instances driven by the controller of main/lib/mpc_jerk.py with its own '
+                                            'constants (N = 13, jerk penalty, free initial acceleration state): qp_quad_kernel<8,2,*,true>, seven-state sweep'}
+                del js
+        except Exception as e:
+            line['mpc_jerk'] = {'error': repr(e)}
         # -------------------------------------------------------------- A* expansion, config 5: 2^20-node Prius frontier, nodes sharded
         try:
             n_all = 1 << 20
@@ -374,6 +391,8 @@ def main():
             line['expand'] = {'nodes_per_s': nps, 'ms': ms, 'nodes': n_all, 'primitives': model.n_prim, 'half_plane_rows': model.n_rows,
                               'obstacles': model.n_obst, 'free_fraction': free_frac,
                               'algorithmic_bytes_per_node': bytes_node, 'hbm_GBps': nps * bytes_node / 1e9,
+                              'traffic': pmc_traffic_bytes('frontier:mpcx::expand_kernel') if world == 1 else None,
+                              'algorithmic_bytes_per_launch': bytes_node * n_all,
                               'hbm_frac': nps * bytes_node / 1e9 / (HBM_PEAK_GBS * world),
                               'fp64_fma_per_node_no_early_out': fma_node, 'fp64_equiv_frac_no_early_out': nps * fma_node * 2 / 1e12 / (FP64_PEAK_TFLOPS * world),
                               'note': 'expand_kernel on a 2^20-node frontier (seed 0, uniform over the junction area), Prius primitives + PriusDimensions, '
