@@ -273,7 +273,7 @@ def main():
     P_rank = sim.P
     mean_iters = it_total / (P_total * args.steps)
     value = args.batch * args.steps / elapsed
-    stage = ((T > 20 or P_rank >= 10240   # MPCX_STAGE_MIN_BATCH of csrc/mpcx_qp.hip
+    stage = ((T > 20 or P_rank >= 11264   # MPCX_STAGE_MIN_BATCH of csrc/mpcx_qp.hip
               ) and os.environ.get('MPCX_QP_KERNEL') != 'wave') \
         or os.environ.get('MPCX_QP_KERNEL') == 'stage'
     flops_qp = qp_flops_stage(T, mean_iters) if stage else qp_flops_condensed(T, mean_iters)

@@ -264,7 +264,7 @@ int32_t mpcx_qp_set_order_hint(mpcx_ctx *ctx, const int32_t *prev_iters /*B or N
                                const int32_t *ref_prev /*B or NULL*/);
 
 /* ---- which kernel solves the QP:
- *   0 = automatic: the stage-structured solver for batches of >= 10240 problems or T > 20 (throughput: 8 problems per
+ *   0 = automatic: the stage-structured solver for batches of >= 11264 problems or T > 20 (throughput: 8 problems per
  *       wavefront, O(T) work per iteration), the condensed solver below that (latency: 0.1-0.3 ms per launch against a
  *       0.4-0.8 ms floor);
  *   1 = condensed (csrc/mpcx_qp.hip, one wavefront per problem, any T <= MPCX_T_MAX, not competitive beyond T = 20);

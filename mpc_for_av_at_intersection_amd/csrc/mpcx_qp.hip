@@ -43,12 +43,12 @@
 // automatic choice: the stage-structured solver wins on throughput (8 problems per wavefront, O(T) work) once the batch fills
 // the chip, the condensed solver on latency (one problem per wavefront: 0.08-0.26 ms per launch up to ~1000 problems against a
 // 0.37-0.78 ms floor); measured crossover on the closed-loop benchmark workload (warm starts, mean 6.2 iterations with a tail to ~20: a small batch is bound by its
-// SLOWEST problem, 41 us per iteration here against ~18 us in the condensed kernel): ~10000 problems at T = 20.  With the trial pass
-// (three quarters of the problems need one pass only) the condensed kernel's work fell more than the stage solver's tail; launch
-// times condensed / stage: 4096 problems 0.40 / 0.64 ms, 8192 0.61 / 0.68, 12288 0.82 / 0.69, 16384 1.04 / 0.71, 24576 1.45 / 0.76.
-// Beyond T = 20 the condensed kernel spills and is never competitive.
+// SLOWEST problem, 41 us per iteration here against 9-18 us in the condensed kernel): ~11500 problems at T = 20.  With the trial pass
+// (three quarters of the problems need one pass only) and the hardest-first queue the condensed kernel's work fell more than the
+// stage solver's tail; launch times condensed / stage: 4096 problems 0.33 / 0.64 ms, 8192 0.51 / 0.68, 10240 0.61 / 0.68,
+// 12288 0.71 / 0.68, 14336 0.83 / 0.70, 16384 0.92 / 0.71.  Beyond T = 20 the condensed kernel spills and is never competitive.
 #ifndef MPCX_STAGE_MIN_BATCH
-#define MPCX_STAGE_MIN_BATCH 10240
+#define MPCX_STAGE_MIN_BATCH 11264
 #endif
 
 namespace mpcx {
@@ -144,6 +144,8 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     if (lane == 0) b = atomicAdd(a.ticket, 1);
     b = __builtin_amdgcn_readfirstlane(b);
     if (b >= a.B) break;
+    if (a.has_order) b = a.order[b];      // hardest first (mpcx_qp_set_order_hint): a wavefront that draws a long problem draws nothing
+                                          // else while the short ones are shared out among the others
     lds_sync();                       // the previous problem's LDS reads are done before this one overwrites the tables
     mpcx_mpc_params P = a.p;
     if (a.has_tune) {                 // wave-uniform row (b comes from readfirstlane): scalar loads
@@ -688,12 +690,13 @@ __global__ __launch_bounds__(256) void qp_order_scatter_kernel(int B, const int3
 }  // namespace mpcx
 
 int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B) {
-    if (B + 2 * mpcx::ORDER_BINS <= ctx->order_cap) return MPCX_OK;
+    const size_t need = 2 * B + 2 * mpcx::ORDER_BINS + 2;       // order | bins | list of given-up problems | its counter and ticket
+    if (need <= ctx->order_cap) return MPCX_OK;
     if (ctx->order) (void)hipFree(ctx->order);
     ctx->order = nullptr; ctx->order_cap = 0;
-    if (hipMalloc((void **)&ctx->order, (B + 2 * mpcx::ORDER_BINS) * sizeof(int32_t)) != hipSuccess)
+    if (hipMalloc((void **)&ctx->order, need * sizeof(int32_t)) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "cannot allocate the work-queue order (%zu entries)", B);
-    ctx->order_cap = B + 2 * mpcx::ORDER_BINS;
+    ctx->order_cap = need;
     return MPCX_OK;
 }
 
@@ -727,7 +730,7 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: the condensed solver has no five-state (lib/mpc_jerk.py) variant; use solver 0 or 2");
     const bool use_stage = solver == 2 || ctx->mpc.model == MPCX_MODEL_JERK5 || (solver == 0 && (T > 20 || B >= MPCX_STAGE_MIN_BATCH));
     const int32_t *order = nullptr;
-    if (use_stage && (ctx->order_hint || ctx->order_now)) {      // only the stage solver draws from a queue that can be ordered
+    if (ctx->order_hint || ctx->order_now) {      // both solvers draw their problems from a queue: longest expected job first
         int32_t rc = mpcx_ensure_order(ctx, (size_t)B);
         if (rc != MPCX_OK) return rc;
         int32_t *hist = ctx->order + B, *cursor = hist + mpcx::ORDER_BINS;
@@ -748,7 +751,8 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         // leaves them untouched and lists them, a small stage-solver launch (a few microseconds when the list is empty) solves them.
         int32_t rc = mpcx_ensure_order(ctx, (size_t)B);
         if (rc != MPCX_OK) return rc;
-        a.defer_fail = 1; a.fail_list = ctx->order; a.fail_count = ctx->order + B;      // the counter lives in the bins' scratch
+        // the list of given-up problems sits behind the order and its bins (B order entries | 2 x ORDER_BINS | B list entries | 2 counters)
+        a.defer_fail = 1; a.fail_list = ctx->order + B + 2 * mpcx::ORDER_BINS; a.fail_count = a.fail_list + B;
         if (hipMemsetAsync(a.fail_count, 0, 2 * sizeof(int32_t), ctx->stream) != hipSuccess)
             return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipMemsetAsync failed");
     }
