@@ -406,15 +406,8 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
             mu = wave_sum_dpp(m01 * (s0 * t0 + s1 * t1) + m23 * (s2 * t2 + s3 * t3)) * minv;
             resn = wave_max_dpp(fmax(fabs(rd) * ign, fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))) * ihn));
         }
-#ifdef MPCX_QP_TRACE
-        if (b == MPCX_QP_TRACE && lane == 0) printf("it %d resn %.3e mu %.3e gnorm %.3e hnorm %.3e\n", it, resn, mu, gnorm, hnorm);
-#endif
-#ifdef MPCX_FIXED_ITERS
-        if (it == MPCX_FIXED_ITERS) { status = MPCX_QP_OPTIMAL; break; }
-#else
         if (accepted) { status = MPCX_QP_OPTIMAL; break; }      // the trial point, with its residuals measured above for the report
         if (!trial && resn <= P.tol && mu <= P.tol) { status = MPCX_QP_OPTIMAL; break; }
-#endif
         // reduced-accuracy acceptance when the iteration cannot continue (the reference accepts ECOS's OPTIMAL_INACCURATE, mpc.py:196)
         const bool loose = !trial && resn <= tol_loose && mu <= tol_loose;
         // stagnation exit: the stationarity residual of badly conditioned instances stalls at its rounding floor while mu keeps
@@ -488,7 +481,6 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 #pragma unroll
                 for (int q = 0; q < PRE; q++) pre[p ^ 1][q] = (j + 2 + q < N) ? sh.cb[p ^ 1][j + 2 + q] : 0.0;
             }
-#ifndef MPCX_SKIP_TRAIL
             {
                 // loads first, then FMAs, then the (volatile) pins: a pin between two loads would serialise them
                 double cv[N];
@@ -499,7 +491,6 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 #pragma unroll
                 for (int kk = j + 2; kk < N; kk++) pin(R[kk]);
             }
-#endif
 #if MPCX_SPLIT
             Rlo[j] = tj;                                                // unit lower factor entry (0 for lanes <= j)
             R[j] = (lane < j) ? R[j] : 0.0;                             // lanes < j keep their unscaled Schur entry
@@ -510,10 +501,8 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
             rinv = rinv_n;
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifndef MPCX_FIXED_ITERS
         if (bad && trial) { trial = false; it--; continue; }    // H itself did not factorise: no trial, the iteration decides
         if (bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; break; }
-#endif
 
         // Everything derived from (u, s, lam) is recomputed here instead of being kept alive across the factorisation (the
         // pins make the compiler treat the inputs as new values): 80 VGPRs of the register file hold the factor.
@@ -530,11 +519,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         // -------- predictor (affine scaling) direction
         double w0 = -m01 * t0 + d0 * rp0, w1 = -m01 * t1 + d1 * rp1, w2 = -m23 * t2 + d2 * rp2, w3 = -m23 * t3 + d3 * rp3;
         double rhs = m01 * (-rd - gt_apply(w0, w1, w2, w3));
-#ifdef MPCX_SKIP_SOLVE
-        double du = m01 * rhs * dinv;
-#else
         double du = m01 * SOLVE(rhs);
-#endif
         double f2 = second_rows(du);
         if (trial) {
             // the four rows of this lane at u + du
@@ -573,11 +558,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         w0 = m01 * (-rc0 + l0 * rp0) * is0; w1 = m01 * (-rc1 + l1 * rp1) * is1;
         w2 = m23 * (-rc2 + l2 * rp2) * is2; w3 = m23 * (-rc3 + l3 * rp3) * is3;
         rhs = m01 * (-rd - gt_apply(w0, w1, w2, w3));
-#ifdef MPCX_SKIP_SOLVE
-        du = m01 * rhs * dinv;
-#else
         du = m01 * SOLVE(rhs);
-#endif
         f2 = second_rows(du);
         const double ds0 = -rp0 - m01 * du, ds1 = -rp1 + m01 * du, ds2 = -rp2 - f2, ds3 = -rp3 + f2;
         const double dl0 = -m01 * (rc0 + l0 * ds0) * is0, dl1 = -m01 * (rc1 + l1 * ds1) * is1;

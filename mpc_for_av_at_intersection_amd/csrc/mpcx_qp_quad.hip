@@ -47,7 +47,7 @@ struct GroupCx {
     __device__ __forceinline__ int count(bool b) const { return __popcll(__ballot(b)); }       // lanes, not groups
     __device__ __forceinline__ double rcp(double v) const { return frcp(v); }
     __device__ __forceinline__ double rcp_fast(double v) const { return frcp1(v); }     // seed + one Newton step
-    // ratio tests only: the hardware seed; the 0.995 step margin is four orders of magnitude wider than its error
+    // ratio tests only: the hardware seed; the 0.001 margin of the step fraction is four orders of magnitude wider than its error
     __device__ __forceinline__ double rcp_seed(double v) const { return __builtin_amdgcn_rcp(v); }
     // phase boundary: LDS values are re-read afterwards instead of being carried in registers across the phase
     __device__ __forceinline__ void fence() const { asm volatile("" ::: "memory"); }
