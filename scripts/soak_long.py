@@ -1,18 +1,20 @@
 """Long closed-loop soak of the bench workload through mpcx_closed_loop_run (dev aid): failures, iteration statistics, sentinel check.
-usage: soak_long.py <stage|wave|auto> <seed> <B> <steps>"""
+usage: soak_long.py <stage|wave|auto> <seed> <B> <steps> [T [jerk]]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 kern, seed, B, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+T = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+jerk = len(sys.argv) > 6 and sys.argv[6] == 'jerk'
 if kern != 'auto': os.environ['MPCX_QP_KERNEL'] = kern
 import numpy as np, torch
 from mpc_for_av_at_intersection_amd.batch import synthetic_batch
-from mpc_for_av_at_intersection_amd.runtime import Context
+from mpc_for_av_at_intersection_amd.runtime import Context, MpcParams
 ctx = Context(0)
-sim = synthetic_batch(ctx, B=B, A=8, T=20, seed=seed)
+sim = synthetic_batch(ctx, B=B, A=8, T=T, seed=seed, mpc=MpcParams.jerk(T=T) if jerk else None)
 fails = 0; itmax = 0; itsum = 0.0
 for k in range(steps):
     sim.step()
     st = sim.sol['status']; it = sim.sol['iters']
     fails += int((st != 0).sum()); itmax = max(itmax, int(it.max())); itsum += float(it.float().mean())
 sim.check()
-print('kernel=%s seed=%d B=%d steps=%d: failures %d, max iters %d, mean iters %.3f, mean speed %.2f' % (kern, seed, B, steps, fails, itmax, itsum / steps, sim.state[:, 2].mean().item()), flush=True)
+print('kernel=%s seed=%d B=%d steps=%d T=%d%s: failures %d, max iters %d, mean iters %.3f, mean speed %.2f' % (kern, seed, B, steps, T, ' jerk' if jerk else '', fails, itmax, itsum / steps, sim.state[:, 2].mean().item()), flush=True)
