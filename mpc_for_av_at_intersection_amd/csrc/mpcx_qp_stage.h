@@ -744,26 +744,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
         }
         const double alpha_aff = cx.gmin(al);
-        const bool was_trial = trial;   // the rest of this round is void for such a group (no corrector, no step, no iteration count)
+        // A trial group goes through the rest of the round with its multipliers still taken as zero: the corrector's right-hand side is
+        // then the predictor's, the second forward sweep repeats the first, and the ordinary step below -- at full length, if no row
+        // was violated -- IS the move to the unconstrained minimiser.  A rejected trial steps nowhere.
+        const bool was_trial = trial;
         if (trial) {
-            const bool blocked = cx.gany(viol) || any_bad;
-            if (running && !blocked) {
-                MPCX_UNROLL
-                for (int ls = 0; ls < SPL; ls++) {
-                    U0[ls] += DA0[ls]; U1[ls] += DA1[ls];
-                    X0[ls] += EA0[ls]; X1[ls] += EA1[ls]; X2[ls] += EA2[ls]; X3[ls] += EA3[ls];
-                }
-                if constexpr (JERK) Z0 += DZA;
-                // rows: the true slack (>= 0 up to rounding; floored so that lam / s stays 0) and zero multipliers
-                double Dnew[SPL];
-                prev_of(U1, Dnew);
-                MPCX_UNROLL
-                for (int ls = 0; ls < SPL; ls++)
-                    MPCX_UNROLL
-                    for (int r = 0; r < ROWS; r++)
-                        if (row_on(ls, r)) { cx.st_s(ls * ROWS + r, fmax(-row_gap(ls, r, Dnew[ls]), 1e-30)); cx.st_l(ls * ROWS + r, 0.0); }
-                accepted = true;
-            }
+            accepted = running && !(cx.gany(viol) || any_bad);
             trial = false;
         }
         // mu_aff = sum (s + a dsa)(lam + a dla) / m = mu + a c1/m + a^2 c2/m
@@ -794,12 +780,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 MPCX_UNROLL
                 for (int r = 0; r < ROWS; r++) {
                     const bool on = row_on(ls, r);
-                    const double s = sv[r], l = on ? lv[r] : 0.0;
+                    const double s = sv[r], l = (on && !was_trial) ? lv[r] : 0.0;
                     const double is = cx.rcp(s);
                     const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
                     const double dsa = on ? -rp - row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]) : 0.0;
                     const double dla = -l - (l * is) * dsa;
-                    const double rc = on ? s * l + alpha_aff * (dsa * dla) - smu : 0.0;
+                    const double rc = (on && !was_trial) ? s * l + alpha_aff * (dsa * dla) - smu : 0.0;
                     RC[ls][r] = rc * is;                                         // rc / s
                     nu[r] = on ? l + (l * rp) * is - rc * is : 0.0;
                 }
@@ -866,7 +852,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             MPCX_UNROLL
             for (int r = 0; r < ROWS; r++) {
                 const bool on = row_on(ls, r);
-                const double s = sv[r], l = on ? lv[r] : 0.0;
+                const double s = sv[r], l = (on && !was_trial) ? lv[r] : 0.0;
                 const double ds = slack_step(ls, r, s);
                 const double dl = on ? -RC[ls][r] - (l * cx.rcp(s)) * ds : 0.0;
                 cx.st_k(ls * ROWS + r, dl);
@@ -876,7 +862,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         }
         cx.fence();
         double alpha = MPCX_STEP_FRACTION * cx.gmin(am);
-        if (alpha > 1.0) alpha = 1.0;
+        if (alpha > 1.0 || was_trial) alpha = 1.0;
         // centrality safeguard: shorten until min s*lam >= 1e-3 * mean at the new point (at most 6 times)
         for (int tr = 0; tr < 6; tr++) {
             double pmin = 1e300, psum = 0.0;
@@ -904,7 +890,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
 #endif
         cx.stamp(8);                    // [local pass E + safeguard]
         // ---- step
-        if (running && !was_trial) {
+        if (running && (!was_trial || accepted)) {
             {
                 double sv[SPL * ROWS], lv[SPL * ROWS], dv[SPL * ROWS];       // every load in flight before the first store
                 MPCX_UNROLL
@@ -914,8 +900,10 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                     MPCX_UNROLL
                     for (int r = 0; r < ROWS; r++) {          // rows that are off have ds = dl = 0
                         const double s = sv[ls * ROWS + r];
-                        cx.st_s(ls * ROWS + r, s + alpha * slack_step(ls, r, s));
-                        cx.st_l(ls * ROWS + r, lv[ls * ROWS + r] + alpha * dv[ls * ROWS + r]);
+                        const double sn = s + alpha * slack_step(ls, r, s), ln = lv[ls * ROWS + r] + alpha * dv[ls * ROWS + r];
+                        // an accepted trial point: the true slack (>= 0 up to rounding; floored so that lam / s stays 0), zero multipliers
+                        cx.st_s(ls * ROWS + r, (was_trial && row_on(ls, r)) ? fmax(sn, 1e-30) : sn);
+                        cx.st_l(ls * ROWS + r, was_trial ? 0.0 : ln);
                     }
             }
             MPCX_UNROLL
@@ -924,7 +912,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 X0[ls] += alpha * E0[ls]; X1[ls] += alpha * E1[ls]; X2[ls] += alpha * E2[ls]; X3[ls] += alpha * E3[ls];
             }
             if constexpr (JERK) Z0 += alpha * DZC;
-            it++;
+            if (!was_trial) it++;
         }
         cx.stamp(9);                    // [update]
     }
