@@ -632,10 +632,16 @@ static void launch_qp(const QpArgs &a, hipStream_t st, int grid) {
 
 namespace mpcx {
 // Work-queue order: longest expected job first.  key = previous iteration count (+ JUMP_BONUS when the problem's reference
-// changed discontinuously since then, e.g. a different path cut: the warm start is then far from the new optimum and such
-// problems take 8 iterations on average instead of 5.3); counting sort by descending key, 64 bins: scratch layout behind the
-// order array is hist[64] | cursor[64].
-constexpr int ORDER_BINS = 64, JUMP_BONUS = 6;
+// changed discontinuously since then, e.g. a different path cut); counting sort by descending key, 64 bins: scratch layout behind
+// the order array is hist[64] | cursor[64].  With the trial pass the previous count of three quarters of the problems is 0, and
+// EVERY problem that turns from unconstrained to hard (>= 10 iterations) between two steps has a moved reference
+// (scripts/predict_probe.py: 100 % of them, 15 % of the moved ones); a launch lasts as long as its last problem, so those must
+// start in round 0, ahead of the known 6-10-iteration ones: bonus 11 (6 until the trial pass: 0.864 -> 0.82 ms per launch;
+// 3 / 8 / 9 / 10 / 12 / 14 / 20: 0.868 / 0.844 / 0.833 / 0.818 / 0.822 / 0.830 / 0.840).
+#ifndef MPCX_JUMP_BONUS
+#define MPCX_JUMP_BONUS 11
+#endif
+constexpr int ORDER_BINS = 64, JUMP_BONUS = MPCX_JUMP_BONUS;
 __device__ __forceinline__ int order_key(int i, const int32_t *hint, const int32_t *now, const int32_t *prev) {
     int k = hint ? hint[i] : 0;
     k = k < 0 ? 0 : k;
