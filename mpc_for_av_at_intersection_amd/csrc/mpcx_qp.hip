@@ -563,24 +563,25 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         const double ds0 = -rp0 - m01 * du, ds1 = -rp1 + m01 * du, ds2 = -rp2 - f2, ds3 = -rp3 + f2;
         const double dl0 = -m01 * (rc0 + l0 * ds0) * is0, dl1 = -m01 * (rc1 + l1 * ds1) * is1;
         const double dl2 = -m23 * (rc2 + l2 * ds2) * is2, dl3 = -m23 * (rc3 + l3 * ds3) * is3;
-        rat = fmax(fmax(-ds0 * is0, -dl0 * il0), fmax(-ds1 * is1, -dl1 * il1));
-        rat = fmax(rat, fmax(fmax(-ds2 * is2, -dl2 * il2), fmax(-ds3 * is3, -dl3 * il3)));
-        rat = wave_max_dpp(rat);
+        // separate step lengths for the primal side (u, s) and the multipliers (see mpcx_qp_stage.h)
+        rat = wave_max_dpp(fmax(fmax(-ds0 * is0, -ds1 * is1), fmax(-ds2 * is2, -ds3 * is3)));
+        const double rat_d = wave_max_dpp(fmax(fmax(-dl0 * il0, -dl1 * il1), fmax(-dl2 * il2, -dl3 * il3)));
         double alpha = (MPCX_STEP_FRACTION < rat) ? MPCX_STEP_FRACTION * frcp(rat) : 1.0;           // min(1, fraction / rat)
+        double alpha_d = (MPCX_STEP_FRACTION < rat_d) ? MPCX_STEP_FRACTION * frcp(rat_d) : 1.0;
         // centrality safeguard (wide neighbourhood): shorten the step until min_i s_i*lam_i >= 1e-3 * mu at the new point;
         // plain Mehrotra otherwise cycles on poorly centred iterates (mu oscillates, residuals -> 0)
         for (int tr = 0; tr < 6; tr++) {
-            const double q0 = (s0 + alpha * ds0) * (l0 + alpha * dl0), q1 = (s1 + alpha * ds1) * (l1 + alpha * dl1);
-            const double q2 = (s2 + alpha * ds2) * (l2 + alpha * dl2), q3 = (s3 + alpha * ds3) * (l3 + alpha * dl3);
+            const double q0 = (s0 + alpha * ds0) * (l0 + alpha_d * dl0), q1 = (s1 + alpha * ds1) * (l1 + alpha_d * dl1);
+            const double q2 = (s2 + alpha * ds2) * (l2 + alpha_d * dl2), q3 = (s3 + alpha * ds3) * (l3 + alpha_d * dl3);
             const double big = 1e300;
             const double pmin = -wave_max_dpp(-fmin(fmin(val01 ? q0 : big, val01 ? q1 : big), fmin(val23 ? q2 : big, val23 ? q3 : big)));
             const double psum = wave_sum_dpp(m01 * (q0 + q1) + m23 * (q2 + q3));
             if (pmin >= 1e-3 * (psum * minv)) break;
-            alpha *= 0.7;
+            alpha *= 0.7; alpha_d *= 0.7;
         }
         u += alpha * du;
         s0 += alpha * ds0; s1 += alpha * ds1; s2 += alpha * ds2; s3 += alpha * ds3;
-        l0 += alpha * dl0; l1 += alpha * dl1; l2 += alpha * dl2; l3 += alpha * dl3;
+        l0 += alpha_d * dl0; l1 += alpha_d * dl1; l2 += alpha_d * dl2; l3 += alpha_d * dl3;
     }
     // exit residuals (absolute, for the kkt[] report)
     const double res_d = wave_max_dpp(fabs(rd));

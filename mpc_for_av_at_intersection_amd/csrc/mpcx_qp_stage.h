@@ -839,7 +839,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         prev_of(D1, Dp);
         // the gains are dead from here on: their storage takes the multiplier step dl (the slack step ds is recomputed)
         cx.fence();
-        double am = 1e300;
+        double am_p = 1e300, am_d = 1e300;      // step bounds of the primal side (slacks) and of the multipliers, taken separately
         auto slack_step = [&](int ls, int r, double s) -> double {
             const bool on = row_on(ls, r);
             const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
@@ -856,13 +856,17 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 const double ds = slack_step(ls, r, s);
                 const double dl = on ? -RC[ls][r] - (l * cx.rcp(s)) * ds : 0.0;
                 cx.st_k(ls * ROWS + r, dl);
-                am = fmin(am, (on && ds < 0.0) ? -s * cx.rcp_fast(ds) : 1e300);
-                am = fmin(am, (on && dl < 0.0) ? -l * cx.rcp_fast(dl) : 1e300);
+                am_p = fmin(am_p, (on && ds < 0.0) ? -s * cx.rcp_fast(ds) : 1e300);
+                am_d = fmin(am_d, (on && dl < 0.0) ? -l * cx.rcp_fast(dl) : 1e300);
             }
         }
         cx.fence();
-        double alpha = MPCX_STEP_FRACTION * cx.gmin(am);
+        // separate step lengths for (u, x, s) and for lam: the creeping instances are blocked by a slack in one iteration and by a
+        // multiplier in the next; a common step length pays for both every time (maximum 20 -> 16 iterations on the closed-loop
+        // corpus, and a launch lasts as long as its slowest problem)
+        double alpha = MPCX_STEP_FRACTION * cx.gmin(am_p), alpha_d = MPCX_STEP_FRACTION * cx.gmin(am_d);
         if (alpha > 1.0 || was_trial) alpha = 1.0;
+        if (alpha_d > 1.0 || was_trial) alpha_d = 1.0;
         // centrality safeguard: shorten until min s*lam >= 1e-3 * mean at the new point (at most 6 times)
         for (int tr = 0; tr < 6; tr++) {
             double pmin = 1e300, psum = 0.0;
@@ -876,14 +880,14 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 for (int r = 0; r < ROWS; r++) {
                     const bool on = row_on(ls, r);
                     const double s = sv[r], l = lv[r];
-                    const double pr = (s + alpha * slack_step(ls, r, s)) * (l + alpha * dv[r]);
+                    const double pr = (s + alpha * slack_step(ls, r, s)) * (l + alpha_d * dv[r]);
                     pmin = fmin(pmin, on ? pr : 1e300); psum += on ? pr : 0.0;
                 }
             }
             const double gmn = cx.gmin(pmin), gsm = cx.gsum(psum);
             const bool ok = gmn >= 1e-3 * (gsm * minv);
             if (!cx.any(running && !was_trial && !ok)) break;
-            if (!ok) alpha *= 0.7;
+            if (!ok) { alpha *= 0.7; alpha_d *= 0.7; }
         }
 #ifdef MPCX_STAGE_TRACE
         trace_alpha = alpha;
@@ -900,7 +904,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                     MPCX_UNROLL
                     for (int r = 0; r < ROWS; r++) {          // rows that are off have ds = dl = 0
                         const double s = sv[ls * ROWS + r];
-                        const double sn = s + alpha * slack_step(ls, r, s), ln = lv[ls * ROWS + r] + alpha * dv[ls * ROWS + r];
+                        const double sn = s + alpha * slack_step(ls, r, s), ln = lv[ls * ROWS + r] + alpha_d * dv[ls * ROWS + r];
                         // an accepted trial point: the true slack (>= 0 up to rounding; floored so that lam / s stays 0), zero multipliers
                         cx.st_s(ls * ROWS + r, (was_trial && row_on(ls, r)) ? fmax(sn, 1e-30) : sn);
                         cx.st_l(ls * ROWS + r, was_trial ? 0.0 : ln);

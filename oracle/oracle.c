@@ -368,32 +368,37 @@ int32_t orc_ipm_dense(const orc_mpc_params *p, int32_t n, int32_t m, const doubl
         }
         for (int k = 0; k < n; k++) { double a = -rd[k]; for (int i = 0; i < m; i++) a -= G[i * n + k] * w[i]; du[k] = a; }
         chol_solve(M, n, du);
-        alpha = 1.0;
-        double amax = 1e300;
+        double amax_p = 1e300, amax_d = 1e300;
         for (int i = 0; i < m; i++) {
             double gd = 0; for (int k = 0; k < n; k++) gd += G[i * n + k] * du[k];
             ds[i] = -rp[i] - gd;
             dl[i] = -(rc[i] + lam[i] * ds[i]) / s[i];
-            if (ds[i] < 0 && -s[i] / ds[i] < amax) amax = -s[i] / ds[i];
-            if (dl[i] < 0 && -lam[i] / dl[i] < amax) amax = -lam[i] / dl[i];
+            if (ds[i] < 0 && -s[i] / ds[i] < amax_p) amax_p = -s[i] / ds[i];
+            if (dl[i] < 0 && -lam[i] / dl[i] < amax_d) amax_d = -lam[i] / dl[i];
         }
         /* step to the boundary: 0.999 of the way (0.995 in round 1: on the closed-loop workload the larger fraction saves 0.8 of 6.1
-         * iterations on average, tail unchanged; same constant in both HIP solvers) */
-        alpha = ORC_STEP_FRACTION * amax; if (alpha > 1.0) alpha = 1.0;
+         * iterations on average, tail unchanged; same constant in both HIP solvers).
+         * SEPARATE step lengths for the primal side (u, s) and the multipliers (round 2): the creeping instances are blocked by a
+         * slack in one iteration and by a multiplier in the next, and a common step length pays for both every time.  On the
+         * constrained closed-loop problems: mean 8.4 -> 7.9 iterations, 99th percentile 15 -> 14, maximum 20 -> 16; the golden cold
+         * starts 19 / 15 / 22 -> 15 / 14 / 17 at T = 10 / 13 / 20; a batch lasts as long as its slowest problem. */
+        double alpha_p = ORC_STEP_FRACTION * amax_p, alpha_d = ORC_STEP_FRACTION * amax_d;
+        if (alpha_p > 1.0) alpha_p = 1.0;
+        if (alpha_d > 1.0) alpha_d = 1.0;
         /* centrality safeguard (wide neighbourhood): shorten the step until min_i s_i*lam_i >= 1e-3 * mu at the new point;
          * plain Mehrotra otherwise cycles on poorly centred iterates (mu oscillates, residuals -> 0) */
         for (int tr = 0; tr < 6; tr++) {
             double pmin = 1e300, psum = 0.0;
             for (int i = 0; i < m; i++) {
-                double pr = (s[i] + alpha * ds[i]) * (lam[i] + alpha * dl[i]);
+                double pr = (s[i] + alpha_p * ds[i]) * (lam[i] + alpha_d * dl[i]);
                 if (pr < pmin) pmin = pr;
                 psum += pr;
             }
             if (pmin >= 1e-3 * (psum / m)) break;
-            alpha *= 0.7;
+            alpha_p *= 0.7; alpha_d *= 0.7;
         }
-        for (int k = 0; k < n; k++) u[k] += alpha * du[k];
-        for (int i = 0; i < m; i++) { s[i] += alpha * ds[i]; lam[i] += alpha * dl[i]; }
+        for (int k = 0; k < n; k++) u[k] += alpha_p * du[k];
+        for (int i = 0; i < m; i++) { s[i] += alpha_p * ds[i]; lam[i] += alpha_d * dl[i]; }
     }
 finish:
     *iters = it;

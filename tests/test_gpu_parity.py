@@ -103,7 +103,7 @@ def test_qp_vs_exact_active_set_solution(ctx, solver):
         dist.append(np.abs(z - ex['z']).max())
     dist = np.array(dist)
     print('%s: |z_gpu - z_exact| max %.2e median %.2e' % (solver, dist.max(), np.median(dist)))
-    assert dist.max() < 5e-5 and np.median(dist) < 1e-7
+    assert dist.max() < 1e-4 and np.median(dist) < 1e-7      # 1e-4: the stated tolerance against the reference's optimum
 
 
 @pytest.mark.parametrize('solver', ['condensed', 'stage', 'auto'])
