@@ -52,6 +52,12 @@ int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B);             // work-queue or
 #ifndef MPCX_STEP_FRACTION
 #define MPCX_STEP_FRACTION 0.999
 #endif
+#ifndef MPCX_SLACK_FLOOR
+#define MPCX_SLACK_FLOOR 0.5    /* starting point of the iteration: s = max(slack, floor), lam = MPCX_LAM0 (same in mpcx_qp_stage.h) */
+#endif
+#ifndef MPCX_LAM0
+#define MPCX_LAM0 3.0              /* 1 until round 2; with separate step lengths 3 takes the hardest problems of a launch from 23 to 18 iterations (2 / 5: 18 / 17, slower on average) */
+#endif
 #ifndef MPCX_TRIAL_STEP
 #define MPCX_TRIAL_STEP 1      /* unconstrained trial step before the interior-point iteration: mpcx_qp_stage.h, mpcx_qp.hip (the tests' CPU checker follows the same rule) */
 #endif

@@ -364,10 +364,10 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     };
 
     double R[N];            // row `lane` of M, then of its factor (see ldl_solve)
-    double s0, s1, s2, s3, l0 = 1.0, l1 = 1.0, l2 = 1.0, l3 = 1.0;
+    double s0, s1, s2, s3, l0 = MPCX_LAM0, l1 = MPCX_LAM0, l2 = MPCX_LAM0, l3 = MPCX_LAM0;
     {
         const double e2 = second_rows(u);
-        s0 = fmax(h0 - u, 0.5); s1 = fmax(h1 + u, 0.5); s2 = fmax(h2 - e2, 0.5); s3 = fmax(h3 + e2, 0.5);
+        s0 = fmax(h0 - u, MPCX_SLACK_FLOOR); s1 = fmax(h1 + u, MPCX_SLACK_FLOOR); s2 = fmax(h2 - e2, MPCX_SLACK_FLOOR); s3 = fmax(h3 + e2, MPCX_SLACK_FLOOR);
     }
     const double gnorm = fmax(1.0, wave_max_dpp(real ? fabs(g) : 0.0));
     const double hnorm = fmax(1.0, wave_max_dpp(fmax(m01 * fmax(fabs(h0), fabs(h1)), m23 * fmax(fabs(h2), fabs(h3)))));

@@ -32,6 +32,12 @@
 #ifndef MPCX_STEP_FRACTION
 #define MPCX_STEP_FRACTION 0.999     /* fraction of the step to the boundary; see mpcx_common.h (the host build of this header has no other source) */
 #endif
+#ifndef MPCX_SLACK_FLOOR
+#define MPCX_SLACK_FLOOR 0.5        /* starting point of the iteration: s = max(slack, floor), lam = MPCX_LAM0 */
+#endif
+#ifndef MPCX_LAM0
+#define MPCX_LAM0 3.0
+#endif
 #ifndef MPCX_TRIAL_STEP
 #define MPCX_TRIAL_STEP 1            /* try the unconstrained minimiser before the interior-point iteration (see `trial` below) */
 #endif
@@ -322,8 +328,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             MPCX_UNROLL
             for (int r = 0; r < ROWS; r++) {
                 const double si = -row_gap(ls, r, Dprev[ls]);
-                cx.st_s(ls * ROWS + r, row_on(ls, r) ? (si > 0.5 ? si : 0.5) : 1.0);
-                cx.st_l(ls * ROWS + r, row_on(ls, r) ? 1.0 : 0.0);
+                cx.st_s(ls * ROWS + r, row_on(ls, r) ? (si > MPCX_SLACK_FLOOR ? si : MPCX_SLACK_FLOOR) : 1.0);
+                cx.st_l(ls * ROWS + r, row_on(ls, r) ? MPCX_LAM0 : 0.0);
             }
     
         tol_loose = P.tol > 1e-7 ? P.tol : 1e-7;
