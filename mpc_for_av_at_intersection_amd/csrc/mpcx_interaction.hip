@@ -290,34 +290,53 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     double b0d = INFINITY, b1d = INFINITY, b2d = INFINITY, b0s = INFINITY, b1s = INFINITY, b2s = INFINITY;
     int b0i = 0x7fffffff, b1i = 0x7fffffff, b2i = 0x7fffffff;
     {
-        double cxp = 0.0, cyp = 0.0, lastx = 0.0, lasty = 0.0;
-        if (lane < n_old) { const double *q = path + 3 * (size_t)(t_old + lane); cxp = q[0]; cyp = q[1]; }
-        for (int i0 = 0; i0 < n_old; i0 += WAVE) {
-            const int i = i0 + lane;
-            double nx = 0.0, ny = 0.0;
-            if (i + WAVE < n_old) { const double *q = path + 3 * (size_t)(t_old + i + WAVE); nx = q[0]; ny = q[1]; }
-            const double px = cxp, py = cyp;
-            double qx = __shfl_up(px, 1, WAVE), qy = __shfl_up(py, 1, WAVE);
-            if (lane == 0) { qx = lastx; qy = lasty; }
-            lastx = rdlane(px, WAVE - 1); lasty = rdlane(py, WAVE - 1);
-            if (i < n_old) {
-                s_cum[i] = (i == 0) ? 0.0 : dist2d(px, py, qx, qy);
-                if (advance) {
-                    const double dx = __dadd_rn(px, -x), dy = __dadd_rn(py, -y);
-                    const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
-                    if (d2 < b2s || b2i == 0x7fffffff) {
-                        const double d = __dsqrt_rn(d2);
-                        if (d < b2d || (d == b2d && i < b2i)) {
-                            if (d < b1d || (d == b1d && i < b1i)) {
-                                b2d = b1d; b2i = b1i; b2s = b1s;
-                                if (d < b0d || (d == b0d && i < b0i)) { b1d = b0d; b1i = b0i; b1s = b0s; b0d = d; b0i = i; b0s = d2; }
-                                else { b1d = d; b1i = i; b1s = d2; }
-                            } else { b2d = d; b2i = i; b2s = d2; }
+        // the points arrive in batches of DEPTH x 64: the loads of the next batch are all in flight while this one is worked on (one
+        // batch deep the pass waited for an L2 round trip per 64 points: it is bound by its loads, not by its arithmetic)
+        constexpr int DEPTH = 4;
+        double bx[DEPTH], by[DEPTH], lastx = 0.0, lasty = 0.0;
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {
+            const int i = k * WAVE + lane;
+            const double *q = path + 3 * (size_t)(t_old + (i < n_old ? i : 0));       // clamped address, selected afterwards
+            const double vx = q[0], vy = q[1];
+            bx[k] = i < n_old ? vx : 0.0; by[k] = i < n_old ? vy : 0.0;
+        }
+        for (int i0 = 0; i0 < n_old; i0 += DEPTH * WAVE) {
+            double nbx[DEPTH], nby[DEPTH];
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++) {
+                const int i = i0 + (DEPTH + k) * WAVE + lane;
+                const double *q = path + 3 * (size_t)(t_old + (i < n_old ? i : 0));
+                const double vx = q[0], vy = q[1];
+                nbx[k] = i < n_old ? vx : 0.0; nby[k] = i < n_old ? vy : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++) {
+                const int i = i0 + k * WAVE + lane;
+                const double px = bx[k], py = by[k];
+                double qx = __shfl_up(px, 1, WAVE), qy = __shfl_up(py, 1, WAVE);
+                if (lane == 0) { qx = lastx; qy = lasty; }
+                lastx = rdlane(px, WAVE - 1); lasty = rdlane(py, WAVE - 1);
+                if (i < n_old) {
+                    s_cum[i] = (i == 0) ? 0.0 : dist2d(px, py, qx, qy);
+                    if (advance) {
+                        const double dx = __dadd_rn(px, -x), dy = __dadd_rn(py, -y);
+                        const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+                        if (d2 < b2s || b2i == 0x7fffffff) {
+                            const double d = __dsqrt_rn(d2);
+                            if (d < b2d || (d == b2d && i < b2i)) {
+                                if (d < b1d || (d == b1d && i < b1i)) {
+                                    b2d = b1d; b2i = b1i; b2s = b1s;
+                                    if (d < b0d || (d == b0d && i < b0i)) { b1d = b0d; b1i = b0i; b1s = b0s; b0d = d; b0i = i; b0s = d2; }
+                                    else { b1d = d; b1i = i; b1s = d2; }
+                                } else { b2d = d; b2i = i; b2s = d2; }
+                            }
                         }
                     }
                 }
             }
-            cxp = nx; cyp = ny;
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++) { bx[k] = nbx[k]; by[k] = nby[k]; }
         }
     }
     ISTAMP(0);      // distance / step-length pass
