@@ -226,27 +226,45 @@ __device__ inline int nearest_index_in_direction(const double *path, int n, int 
     if (len == 2) return start + 1;
     double b0d = INFINITY, b1d = INFINITY, b2d = INFINITY, b2s = INFINITY, b1s = INFINITY, b0s = INFINITY;
     int b0i = 0x7fffffff, b1i = 0x7fffffff, b2i = 0x7fffffff;
-    double cx = 0.0, cy = 0.0;
-    if (lane < len) { const double *q = path + 3 * (size_t)(start + lane); cx = q[0]; cy = q[1]; }
-    for (int i0 = 0; i0 < len; i0 += WAVE) {
-        const int i = i0 + lane;
-        double nx = 0.0, ny = 0.0;
-        if (i + WAVE < len) { const double *q = path + 3 * (size_t)(start + i + WAVE); nx = q[0]; ny = q[1]; }
-        if (i < len) {
-            const double dx = __dadd_rn(cx, -x), dy = __dadd_rn(cy, -y);
-            const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
-            if (d2 < b2s || b2i == 0x7fffffff) {
-                const double d = __dsqrt_rn(d2);
-                if (d < b2d || (d == b2d && i < b2i)) {
-                    if (d < b1d || (d == b1d && i < b1i)) {
-                        b2d = b1d; b2i = b1i; b2s = b1s;
-                        if (d < b0d || (d == b0d && i < b0i)) { b1d = b0d; b1i = b0i; b1s = b0s; b0d = d; b0i = i; b0s = d2; }
-                        else { b1d = d; b1i = i; b1s = d2; }
-                    } else { b2d = d; b2i = i; b2s = d2; }
+    // the points arrive in batches of DEPTH x 64 with the next batch's loads all in flight (one batch deep the scan waited for an
+    // L2 round trip per 64 points: there is almost no arithmetic to hide it behind)
+    constexpr int DEPTH = 4;
+    double bx[DEPTH], by[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) {
+        const int i = k * WAVE + lane;
+        const double *q = path + 3 * (size_t)(start + (i < len ? i : 0));        // clamped address, selected afterwards
+        const double vx = q[0], vy = q[1];
+        bx[k] = vx; by[k] = vy;
+    }
+    for (int i0 = 0; i0 < len; i0 += DEPTH * WAVE) {
+        double nbx[DEPTH], nby[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {
+            const int i = i0 + (DEPTH + k) * WAVE + lane;
+            const double *q = path + 3 * (size_t)(start + (i < len ? i : 0));
+            nbx[k] = q[0]; nby[k] = q[1];
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {
+            const int i = i0 + k * WAVE + lane;
+            if (i < len) {
+                const double dx = __dadd_rn(bx[k], -x), dy = __dadd_rn(by[k], -y);
+                const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+                if (d2 < b2s || b2i == 0x7fffffff) {
+                    const double d = __dsqrt_rn(d2);
+                    if (d < b2d || (d == b2d && i < b2i)) {
+                        if (d < b1d || (d == b1d && i < b1i)) {
+                            b2d = b1d; b2i = b1i; b2s = b1s;
+                            if (d < b0d || (d == b0d && i < b0i)) { b1d = b0d; b1i = b0i; b1s = b0s; b0d = d; b0i = i; b0s = d2; }
+                            else { b1d = d; b1i = i; b1s = d2; }
+                        } else { b2d = d; b2i = i; b2s = d2; }
+                    }
                 }
             }
         }
-        cx = nx; cy = ny;
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) { bx[k] = nbx[k]; by[k] = nby[k]; }
     }
     int bi[3];
 #pragma unroll
