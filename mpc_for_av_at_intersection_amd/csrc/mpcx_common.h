@@ -62,6 +62,21 @@ int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B);             // work-queue or
 #define MPCX_TRIAL_STEP 1      /* unconstrained trial step before the interior-point iteration: mpcx_qp_stage.h, mpcx_qp.hip (the tests' CPU checker follows the same rule) */
 #endif
 
+/* active-set polish at the end of the interior-point iteration: the rule and the constants are those of mpcx_qp_stage.h (the host
+   build of that header has no other source; oracle.c carries the same values as ORC_POLISH_*) */
+#ifndef MPCX_POLISH
+#define MPCX_POLISH 1
+#endif
+#ifndef MPCX_POLISH_MU
+#define MPCX_POLISH_MU 1e-6
+#define MPCX_POLISH_RP 1e-6
+#define MPCX_POLISH_RD 1e-3
+#define MPCX_POLISH_RHO 1e8
+#define MPCX_POLISH_TRIES 3
+#define MPCX_POLISH_EPS_L 1e-9
+#define MPCX_POLISH_EPS_G 1e-9
+#endif
+
 namespace mpcx {
 
 constexpr int WAVE = 64;

@@ -386,6 +386,10 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     // trial step (see mpcx_qp_stage.h): the first pass runs with every multiplier taken as zero, so that M = H and the
     // predictor direction leads to the unconstrained minimiser; if that point violates no row it is the solution (0 iterations)
     bool trial = feasible0 && MPCX_TRIAL_STEP != 0, accepted = false;
+    // active-set polish (see MPCX_POLISH in mpcx_qp_stage.h): a pass like the trial pass, with weight rho on the rows of the active set
+    // (pm0..pm3: this lane's four rows) and lam_e + rho gap as their linear term; accepted if its end point is a KKT point
+    bool polish = false, skip_test = false, pm0 = false, pm1 = false, pm2 = false, pm3 = false;
+    int ptries = 0, pend = 0;
 
     for (it = 0; it <= max_iter; it++) {
         // -------- H u from the PRISTINE Hessian (restore the band entries the previous iteration patched)
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
 #pragma unroll
         for (int j = 0; j < N; j++) hu = fma(sh.H[j * N + li], sh.ub[j], hu);
         // -------- residuals
-        double resn;
+        double resn, resd_n, resp_n;
         {
             const double e2 = second_rows(u);
             const double t0 = trial ? 0.0 : l0, t1 = trial ? 0.0 : l1, t2 = trial ? 0.0 : l2, t3 = trial ? 0.0 : l3;
@@ -404,17 +408,27 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
             rp0 = m01 * (u + s0 - h0); rp1 = m01 * (-u + s1 - h1);
             rp2 = m23 * (e2 + s2 - h2); rp3 = m23 * (-e2 + s3 - h3);
             mu = wave_sum_dpp(m01 * (s0 * t0 + s1 * t1) + m23 * (s2 * t2 + s3 * t3)) * minv;
-            resn = wave_max_dpp(fmax(fabs(rd) * ign, fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))) * ihn));
+            resd_n = wave_max_dpp(fabs(rd) * ign);
+            resp_n = wave_max_dpp(fmax(fmax(fabs(rp0), fabs(rp1)), fmax(fabs(rp2), fabs(rp3))) * ihn);
+            resn = fmax(resd_n, resp_n);
         }
-        if (accepted) { status = MPCX_QP_OPTIMAL; break; }      // the trial point, with its residuals measured above for the report
-        if (!trial && resn <= P.tol && mu <= P.tol) { status = MPCX_QP_OPTIMAL; break; }
+        if (accepted) { status = MPCX_QP_OPTIMAL; break; }      // the trial / polish point, with its residuals measured above for the report
         // reduced-accuracy acceptance when the iteration cannot continue (the reference accepts ECOS's OPTIMAL_INACCURATE, mpc.py:196)
         const bool loose = !trial && resn <= tol_loose && mu <= tol_loose;
-        // stagnation exit: the stationarity residual of badly conditioned instances stalls at its rounding floor while mu keeps
-        // collapsing; after 4 consecutive reduced-accuracy iterates stop before the factorisation degrades them
-        loose_run = loose ? loose_run + 1 : 0;
-        if (loose_run >= 4) { status = MPCX_QP_OPTIMAL; break; }
-        if (!trial && it == max_iter) { if (loose) status = MPCX_QP_OPTIMAL; break; }
+        if (!trial && !polish && !skip_test) {       // the exit tests, once per iterate
+            const bool conv = resn <= P.tol && mu <= P.tol;
+            // stagnation exit: the stationarity residual of badly conditioned instances stalls at its rounding floor while mu keeps
+            // collapsing; after 4 consecutive reduced-accuracy iterates stop before the factorisation degrades them
+            loose_run = loose ? loose_run + 1 : 0;
+            const bool stop_ok = conv || loose_run >= 4 || (it == max_iter && loose);
+            const bool stop_fail = it == max_iter && !loose;
+            const bool near = mu <= MPCX_POLISH_MU && resp_n <= MPCX_POLISH_RP && resd_n <= MPCX_POLISH_RD;
+            if (MPCX_POLISH != 0 && (near || stop_ok || stop_fail)) {
+                polish = true; ptries = 0; pend = stop_ok ? 1 : (stop_fail ? 2 : 0);
+                pm0 = val01 && s0 < l0; pm1 = val01 && s1 < l1; pm2 = val23 && s2 < l2; pm3 = val23 && s3 < l3;
+            } else if (stop_ok) { status = MPCX_QP_OPTIMAL; break; }
+            else if (stop_fail) break;
+        }
 
         // -------- row of M = H + G'DG: the band part (diagonal + steer tridiagonal) is written into LDS so that the row
         // reads back without per-element selects; the accel block adds dt^2 * min(S_i, S_j)
@@ -422,12 +436,13 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         {
             const double is0 = frcp1(s0), is1 = frcp1(s1), is2 = frcp1(s2), is3 = frcp1(s3);
             const double t0 = trial ? 0.0 : l0, t1 = trial ? 0.0 : l1, t2 = trial ? 0.0 : l2, t3 = trial ? 0.0 : l3;
-            const double r23 = m23 * (t2 * is2 + t3 * is3);
+            const double r23 = polish ? ((pm2 ? MPCX_POLISH_RHO : 0.0) + (pm3 ? MPCX_POLISH_RHO : 0.0)) : m23 * (t2 * is2 + t3 * is3);
             S = scan_down32(ma * r23, lane);             // accel lanes: sum_{j>=k} (d2+d3)_j ; elsewhere 0
             const double r_own = kind ? r23 : 0.0;
             const double r_prev = k0m * lane_prev(r_own);
             sh.sb[lane] = S;
-            sh.H[i_d] = h_d + (m01 * (t0 * is0 + t1 * is1) + r_own + r_prev);
+            const double r01 = polish ? ((pm0 ? MPCX_POLISH_RHO : 0.0) + (pm1 ? MPCX_POLISH_RHO : 0.0)) : m01 * (t0 * is0 + t1 * is1);
+            sh.H[i_d] = h_d + (r01 + r_own + r_prev);
             sh.H[i_hi] = h_hi - r_own;
             sh.H[i_lo] = h_lo - r_prev;
         }
@@ -502,6 +517,16 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (bad && trial) { trial = false; it--; continue; }    // H itself did not factorise: no trial, the iteration decides
+        if (bad && polish) {                                    // counts as a rejected polish pass
+            ptries++;
+            if (ptries >= MPCX_POLISH_TRIES) {
+                polish = false;
+                if (pend == 1) { status = MPCX_QP_OPTIMAL; break; }
+                if (pend == 2) break;
+                skip_test = true;
+            }
+            it--; continue;
+        }
         if (bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; break; }
 
         // Everything derived from (u, s, lam) is recomputed here instead of being kept alive across the factorisation (the
@@ -518,9 +543,40 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         }
         // -------- predictor (affine scaling) direction
         double w0 = -m01 * t0 + d0 * rp0, w1 = -m01 * t1 + d1 * rp1, w2 = -m23 * t2 + d2 * rp2, w3 = -m23 * t3 + d3 * rp3;
+        // lam_e: the iterate's multiplier where the iterate itself holds the row active (rows that entered the set later: 0)
+        const double e0 = (s0 < l0) ? l0 : 0.0, e1 = (s1 < l1) ? l1 : 0.0, e2l = (s2 < l2) ? l2 : 0.0, e3 = (s3 < l3) ? l3 : 0.0;
+        if (polish) {       // rd above carries G' lam: take it out, put the active rows' lam_e + rho gap in (gap = rp - s)
+            w0 = -m01 * l0 + (pm0 ? e0 + MPCX_POLISH_RHO * (rp0 - s0) : 0.0); w1 = -m01 * l1 + (pm1 ? e1 + MPCX_POLISH_RHO * (rp1 - s1) : 0.0);
+            w2 = -m23 * l2 + (pm2 ? e2l + MPCX_POLISH_RHO * (rp2 - s2) : 0.0); w3 = -m23 * l3 + (pm3 ? e3 + MPCX_POLISH_RHO * (rp3 - s3) : 0.0);
+        }
         double rhs = m01 * (-rd - gt_apply(w0, w1, w2, w3));
         double du = m01 * SOLVE(rhs);
         double f2 = second_rows(du);
+        if (polish) {
+            const double un = u + du, en = e2u + f2;
+            const double g0 = un - h0, g1 = -un - h1, g2 = en - h2, g3 = -en - h3;          // row gaps at the end point
+            const double n0 = e0 + MPCX_POLISH_RHO * g0, n1 = e1 + MPCX_POLISH_RHO * g1, n2 = e2l + MPCX_POLISH_RHO * g2, n3 = e3 + MPCX_POLISH_RHO * g3;
+            const bool ng0 = pm0 && n0 < -MPCX_POLISH_EPS_L, ng1 = pm1 && n1 < -MPCX_POLISH_EPS_L, ng2 = pm2 && n2 < -MPCX_POLISH_EPS_L, ng3 = pm3 && n3 < -MPCX_POLISH_EPS_L;
+            const bool vi0 = !pm0 && val01 && g0 > MPCX_POLISH_EPS_G, vi1 = !pm1 && val01 && g1 > MPCX_POLISH_EPS_G;
+            const bool vi2 = !pm2 && val23 && g2 > MPCX_POLISH_EPS_G, vi3 = !pm3 && val23 && g3 > MPCX_POLISH_EPS_G;
+            if (__ballot(ng0 || ng1 || ng2 || ng3 || vi0 || vi1 || vi2 || vi3) == 0ull) {
+                u = un;
+                s0 = fmax(-g0, 1e-30); s1 = fmax(-g1, 1e-30); s2 = fmax(-g2, 1e-30); s3 = fmax(-g3, 1e-30);
+                l0 = pm0 ? fmax(n0, 0.0) : 0.0; l1 = pm1 ? fmax(n1, 0.0) : 0.0; l2 = pm2 ? fmax(n2, 0.0) : 0.0; l3 = pm3 ? fmax(n3, 0.0) : 0.0;
+                accepted = true; polish = false;
+            } else {
+                pm0 = (pm0 || vi0) && !ng0; pm1 = (pm1 || vi1) && !ng1; pm2 = (pm2 || vi2) && !ng2; pm3 = (pm3 || vi3) && !ng3;
+                ptries++;
+                if (ptries >= MPCX_POLISH_TRIES) {
+                    polish = false;
+                    if (pend == 1) { status = MPCX_QP_OPTIMAL; break; }
+                    if (pend == 2) break;
+                    skip_test = true;               // the iteration goes on from the iterate the exit tests have already seen
+                }
+            }
+            it--;                                   // not an iteration
+            continue;
+        }
         if (trial) {
             // the four rows of this lane at u + du
             const double un = u + du, en = e2u + f2;
@@ -582,6 +638,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         u += alpha * du;
         s0 += alpha * ds0; s1 += alpha * ds1; s2 += alpha * ds2; s3 += alpha * ds3;
         l0 += alpha_d * dl0; l1 += alpha_d * dl1; l2 += alpha_d * dl2; l3 += alpha_d * dl3;
+        skip_test = false;
     }
     // exit residuals (absolute, for the kkt[] report)
     const double res_d = wave_max_dpp(fabs(rd));

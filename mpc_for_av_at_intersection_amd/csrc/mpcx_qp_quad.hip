@@ -90,7 +90,7 @@ struct QueueSrc {
 #define MPCX_REFILL_GROUPS 2
 #endif
     __device__ __forceinline__ int refill_min() const { return MPCX_REFILL_GROUPS * LQ; }   // in lanes
-    __device__ __forceinline__ long max_rounds() const { return ((long)a.B + 2) * (long)(a.p.max_iter + 6); }
+    __device__ __forceinline__ long max_rounds() const { return ((long)a.B + 2) * (long)(a.p.max_iter + 6) * (MPCX_POLISH_TRIES + 1); }
     template <class Cx>
     __device__ __forceinline__ bool fetch(Cx &cx, mpcx_mpc_params &P, mpcx_stage::Problem &pb) const {
         int t = 0;

@@ -41,6 +41,27 @@
 #ifndef MPCX_TRIAL_STEP
 #define MPCX_TRIAL_STEP 1            /* try the unconstrained minimiser before the interior-point iteration (see `trial` below) */
 #endif
+/* Active-set polish (round 3; same rule in oracle.c and in the condensed solver): an interior-point iterate sits ~sqrt(mu) from the optimum
+   on weakly active rows, and the low curvature of the input cost (2R = 0.02) amplifies that -- up to 1e-3 on the hard closed-loop
+   problems at the reduced-accuracy exit.  Once the iterate is close (mu <= MPCX_POLISH_MU with small residuals, or at any exit) the
+   rows with s < lam are taken as the active set and ONE augmented-Lagrangian solve is made on it -- a round whose barrier weights
+   are rho on the active rows and 0 elsewhere, with lam_a + rho gap_a as the rows' linear term: the trial pass below is the special
+   case "no active row".  The end point is accepted only if it is a KKT point (new multipliers lam_a + rho gap_a' >= 0, no other
+   row violated): then it is the minimiser up to |lam - lam*| / rho.  Otherwise rows with a negative multiplier leave the set,
+   violated rows enter it, and the round is repeated, MPCX_POLISH_TRIES times in all; after that nothing is kept and the iteration goes on
+   (or ends with its own iterate).  Polish rounds are not counted as iterations. */
+#ifndef MPCX_POLISH
+#define MPCX_POLISH 1
+#endif
+#ifndef MPCX_POLISH_MU
+#define MPCX_POLISH_MU 1e-6         /* entry: mu, primal residual / hnorm, dual residual / gnorm below these (or any exit) */
+#define MPCX_POLISH_RP 1e-6
+#define MPCX_POLISH_RD 1e-3
+#define MPCX_POLISH_RHO 1e8         /* penalty of the augmented-Lagrangian solve */
+#define MPCX_POLISH_TRIES 3
+#define MPCX_POLISH_EPS_L 1e-9      /* a new multiplier below -EPS_L / a gap above EPS_G rejects the point */
+#define MPCX_POLISH_EPS_G 1e-9
+#endif
 #define MPCX_UNROLL _Pragma("unroll")
 #define MPCX_NOUNROLL _Pragma("nounroll")
 
@@ -95,8 +116,14 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     // step, reports 0 iterations and is done; about two thirds of the closed-loop problems end this way instead of spending four
     // interior-point iterations walking lam from 1 to 1e-10.  Otherwise nothing is kept and the iteration starts as before.
     bool trial = false, accepted = false;
+    // polish rounds (see MPCX_POLISH above): the current active set, one byte of row bits per slot; rounds tried; what the group does
+    // if no round is accepted (0: the iteration goes on, 1: it ends OPTIMAL with its own iterate, 2: it ends as it is -- MAXITER)
+    bool polish = false, skip_test = false;
+    int ptries = 0, pend = 0;
+    uint8_t pmask[SPL] = {};
 #ifdef MPCX_STAGE_TRACE
     double trace_alpha = 0.0, trace_aff = 0.0, trace_sigma = 0.0;       // dev build: per-iteration history of one problem
+    int trace_n = 0;
 #endif
 
 #define WV(ls) (act[ls] ? (ended[ls] ? wv_end : wv_run) : 0.0)
@@ -339,6 +366,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         running = valid && feasible0;
         trial = running && MPCX_TRIAL_STEP != 0;
         accepted = false;
+        polish = false; skip_test = false; ptries = 0; pend = 0;
     };
     // ------------------------------------------------------------------ a finished problem leaves: u, x = rollout of the linear model
     auto emit = [&]() {
@@ -394,10 +422,15 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                     const bool on = row_on(ls, r);
                     const double s = sv[r], l = trial ? 0.0 : lv[r];
                     const double is = cx.rcp(s);
-                    const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
-                    const double d = on ? l * is : 0.0;
+                    const double gap = row_gap(ls, r, Dprev[ls]);
+                    const double rp = on ? s + gap : 0.0;
+                    // a polish round: weight rho on the rows of the active set, their linear term lam_e + rho gap (lam_e = the
+                    // iterate's multiplier where the iterate itself had the row active, 0 for rows that entered later)
+                    const bool pa = polish && ((pmask[ls] >> r) & 1);
+                    const double d = polish ? (pa ? MPCX_POLISH_RHO : 0.0) : (on ? l * is : 0.0);
                     dd[r] = d;
-                    lam[r] = on ? l : 0.0; nu[r] = d * rp;
+                    lam[r] = on ? l : 0.0;
+                    nu[r] = polish ? (pa ? ((s < l) ? l : 0.0) + MPCX_POLISH_RHO * gap : 0.0) : d * rp;
                     mu_s += on ? s * l : 0.0;
                     rp_m = fmax(rp_m, fabs(rp));
                 }
@@ -433,28 +466,47 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             for (int ls = 0; ls < SPL; ls++) rd_m = fmax(rd_m, fmax(fabs(O0[ls]), fabs(O1[ls])));
             const double n_rd = cx.gmax(rd_m), n_rp = cx.gmax(rp_m);
             n_mu = cx.gsum(mu_s) * minv;
-            if (running) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
-            const bool test = running && !trial && (pass == 0 || fresh);      // a group takes the exit tests once per iterate
+            if (running && !polish) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
+            const bool test = running && !trial && !polish && !skip_test && (pass == 0 || fresh);      // a group takes the exit tests once per iterate
             if (test && accepted) { status = MPCX_QP_OPTIMAL; running = false; }     // residuals of the accepted trial point: measured above, for the report
 #ifdef MPCX_STAGE_TRACE
             if (test) cx.trace(it, res_d, res_p, mu, trace_alpha, trace_aff, trace_sigma);
 #endif
             cx.stamp(2);                    // [costate sweep]
             // ---- exit tests (uniform per group)
-            if (test && running) {
-                if (res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol) { status = MPCX_QP_OPTIMAL; running = false; }
-            }
-            if (test && running) {
-                loose = (res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose);
-                loose_run = loose ? loose_run + 1 : 0;
-                if (loose_run >= 4) { status = MPCX_QP_OPTIMAL; running = false; }
-                else if (it == max_iter) { if (loose) status = MPCX_QP_OPTIMAL; running = false; }
+            bool entered = false;           // the group starts polishing in this round: its row pass has to be redone with the polish weights
+            {
+                // the rows the iterate holds active (s < lam), in case the group starts polishing (loads unconditional, see rows_of)
+                uint8_t am[SPL];
+                MPCX_UNROLL
+                for (int ls = 0; ls < SPL; ls++) {
+                    double sv[ROWS], lv[ROWS];
+                    rows_of(ls, sv, lv);
+                    unsigned m8 = 0;
+                    MPCX_UNROLL
+                    for (int r = 0; r < ROWS; r++) m8 |= (row_on(ls, r) && sv[r] < lv[r]) ? (1u << r) : 0u;
+                    am[ls] = (uint8_t)m8;
+                }
+                if (test && running) {
+                    const bool conv = res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol;
+                    loose = (res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose);
+                    loose_run = loose ? loose_run + 1 : 0;
+                    const bool stop_ok = conv || loose_run >= 4 || (it == max_iter && loose);
+                    const bool stop_fail = it == max_iter && !loose;
+                    const bool near = mu <= MPCX_POLISH_MU && res_p <= MPCX_POLISH_RP * hnorm && res_d <= MPCX_POLISH_RD * gnorm;
+                    if (MPCX_POLISH != 0 && (near || stop_ok || stop_fail)) {
+                        polish = true; entered = true; ptries = 0; pend = stop_ok ? 1 : (stop_fail ? 2 : 0);
+                        MPCX_UNROLL
+                        for (int ls = 0; ls < SPL; ls++) pmask[ls] = am[ls];
+                    } else if (stop_ok) { status = MPCX_QP_OPTIMAL; running = false; }
+                    else if (stop_fail) running = false;
+                }
             }
             if (pass == 1) break;
             // hand-in / draw / set-up costs the whole wavefront a few thousand instructions: do it when at least `refill_min`
             // groups are waiting, or when nobody is running any more
             const bool need = !running && !drained;
-            if (!(cx.count(need) >= src.refill_min() || (cx.any(need) && !cx.any(running)))) break;
+            if (!(cx.count(need) >= src.refill_min() || (cx.any(need) && !cx.any(running)) || cx.any(entered))) break;
             fresh = false;
             if (need) {                  // uniform within a group: the DPP operations inside stay inside the group
                 if (have) emit();
@@ -662,7 +714,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
         }
         const bool any_bad = cx.gany(bad);
-        if (running && !trial && any_bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; running = false; }
+        if (running && !trial && !polish && any_bad) { status = loose ? MPCX_QP_OPTIMAL : MPCX_QP_NUMERIC; running = false; }
 
         // forward sweep with gains (K, kk): fills the direction (du, dx_{t+1})
         auto forward = [&](const double (&k0)[SPL], const double (&k1)[SPL], double dz0, double (&D0)[SPL], double (&D1)[SPL],
@@ -727,6 +779,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         prev_of(DA1, DAp);
         double al = 1.0, c1 = 0.0, c2 = 0.0;
         bool viol = false;              // trial: a row is violated at the predictor's end point
+        uint8_t pneg[SPL] = {}, pvio[SPL] = {};     // polish: active rows whose new multiplier is negative / other rows violated at the end point
         // per row, recomputed from (s, lam, u, x) wherever needed instead of being kept: rp = s + gap, d = lam / s
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++) {
@@ -742,6 +795,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 const double dsa = on ? -rp - dir : 0.0;
                 const double dla = -l - d * dsa;
                 viol = viol || (on && !(gap + dir <= 0.0));
+                {
+                    const bool pa = (pmask[ls] >> r) & 1;
+                    const double ln = ((s < l) ? l : 0.0) + MPCX_POLISH_RHO * (gap + dir);
+                    pneg[ls] |= (pa && ln < -MPCX_POLISH_EPS_L) ? (1u << r) : 0u;
+                    pvio[ls] |= (!pa && on && gap + dir > MPCX_POLISH_EPS_G) ? (1u << r) : 0u;
+                }
                 // ratio tests: any value <= the exact ratio is a valid step bound, the 0.001 margin of MPCX_STEP_FRACTION is 12 orders above rcp_fast's error
                 al = fmin(al, (on && dsa < 0.0) ? -s * cx.rcp_fast(dsa) : 1.0);
                 al = fmin(al, (on && dla < 0.0) ? -l * cx.rcp_fast(dla) : 1.0);
@@ -757,6 +816,37 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         if (trial) {
             accepted = running && !(cx.gany(viol) || any_bad);
             trial = false;
+        }
+        // a polish round: accepted if the end point is a KKT point; otherwise the active set is corrected and the round repeated, or the
+        // group gives up polishing -- the iterate has not been touched
+        const bool was_polish = polish;
+        if (polish) {
+            bool ch = false;
+            MPCX_UNROLL
+            for (int ls = 0; ls < SPL; ls++) ch = ch || pneg[ls] != 0 || pvio[ls] != 0;
+            const bool rej = cx.gany(ch) || any_bad;
+            accepted = running && !rej;
+#ifdef MPCX_STAGE_TRACE
+            {
+                double na = 0.0, nn = 0.0, nv = 0.0;
+                MPCX_UNROLL
+                for (int ls = 0; ls < SPL; ls++) { na += __builtin_popcount(pmask[ls]); nn += __builtin_popcount(pneg[ls]); nv += __builtin_popcount(pvio[ls]); }
+                cx.trace(24 + trace_n++, (double)it, (double)ptries, cx.gsum(na), cx.gsum(nn), cx.gsum(nv), (any_bad ? 100.0 : 0.0) + (double)guard);
+            }
+#endif
+            if (rej) {
+                if (!any_bad) {
+                    MPCX_UNROLL
+                    for (int ls = 0; ls < SPL; ls++) pmask[ls] = (uint8_t)((pmask[ls] | pvio[ls]) & ~pneg[ls]);
+                }
+                ptries++;
+                if (ptries >= MPCX_POLISH_TRIES) {
+                    polish = false;
+                    if (pend == 1) { status = MPCX_QP_OPTIMAL; running = false; }
+                    else if (pend == 2) running = false;
+                    else skip_test = true;              // the iteration goes on from the iterate the exit tests have already seen
+                }
+            } else polish = false;
         }
         // mu_aff = sum (s + a dsa)(lam + a dla) / m = mu + a c1/m + a^2 c2/m
         const double mu_aff = n_mu + alpha_aff * (cx.gsum(c1) * minv) + alpha_aff * alpha_aff * (cx.gsum(c2) * minv);
@@ -791,9 +881,11 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                     const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
                     const double dsa = on ? -rp - row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]) : 0.0;
                     const double dla = -l - (l * is) * dsa;
-                    const double rc = (on && !was_trial) ? s * l + alpha_aff * (dsa * dla) - smu : 0.0;
+                    const double rc = (on && !was_trial && !was_polish) ? s * l + alpha_aff * (dsa * dla) - smu : 0.0;
                     RC[ls][r] = rc * is;                                         // rc / s
-                    nu[r] = on ? l + (l * rp) * is - rc * is : 0.0;
+                    const bool pa = was_polish && ((pmask[ls] >> r) & 1);       // an accepted polish round keeps its mask: same linear terms as its predictor
+                    nu[r] = was_polish ? (pa ? ((s < l) ? l : 0.0) + MPCX_POLISH_RHO * row_gap(ls, r, Dprev[ls]) : 0.0)
+                                       : (on ? l + (l * rp) * is - rc * is : 0.0);
                 }
                 C01[ls] = nu[0] - nu[1]; C23[ls] = nu[2] - nu[3]; C45[ls] = nu[4] - nu[5]; C67[ls] = nu[6] - nu[7];
             }
@@ -871,8 +963,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         // multiplier in the next; a common step length pays for both every time (maximum 20 -> 16 iterations on the closed-loop
         // corpus, and a launch lasts as long as its slowest problem)
         double alpha = MPCX_STEP_FRACTION * cx.gmin(am_p), alpha_d = MPCX_STEP_FRACTION * cx.gmin(am_d);
-        if (alpha > 1.0 || was_trial) alpha = 1.0;
-        if (alpha_d > 1.0 || was_trial) alpha_d = 1.0;
+        if (alpha > 1.0 || was_trial || was_polish) alpha = 1.0;
+        if (alpha_d > 1.0 || was_trial || was_polish) alpha_d = 1.0;
         // centrality safeguard: shorten until min s*lam >= 1e-3 * mean at the new point (at most 6 times)
         for (int tr = 0; tr < 6; tr++) {
             double pmin = 1e300, psum = 0.0;
@@ -892,15 +984,15 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             }
             const double gmn = cx.gmin(pmin), gsm = cx.gsum(psum);
             const bool ok = gmn >= 1e-3 * (gsm * minv);
-            if (!cx.any(running && !was_trial && !ok)) break;
-            if (!ok) { alpha *= 0.7; alpha_d *= 0.7; }
+            if (!cx.any(running && !was_trial && !was_polish && !ok)) break;
+            if (!ok && !was_trial && !was_polish) { alpha *= 0.7; alpha_d *= 0.7; }      // (a trial / polish group takes the full step or none)
         }
 #ifdef MPCX_STAGE_TRACE
         trace_alpha = alpha;
 #endif
         cx.stamp(8);                    // [local pass E + safeguard]
         // ---- step
-        if (running && (!was_trial || accepted)) {
+        if (running && (!(was_trial || was_polish) || accepted)) {
             {
                 double sv[SPL * ROWS], lv[SPL * ROWS], dv[SPL * ROWS];       // every load in flight before the first store
                 MPCX_UNROLL
@@ -910,10 +1002,14 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                     MPCX_UNROLL
                     for (int r = 0; r < ROWS; r++) {          // rows that are off have ds = dl = 0
                         const double s = sv[ls * ROWS + r];
-                        const double sn = s + alpha * slack_step(ls, r, s), ln = lv[ls * ROWS + r] + alpha_d * dv[ls * ROWS + r];
-                        // an accepted trial point: the true slack (>= 0 up to rounding; floored so that lam / s stays 0), zero multipliers
-                        cx.st_s(ls * ROWS + r, (was_trial && row_on(ls, r)) ? fmax(sn, 1e-30) : sn);
-                        cx.st_l(ls * ROWS + r, was_trial ? 0.0 : ln);
+                        const double l = lv[ls * ROWS + r];
+                        const double sn = s + alpha * slack_step(ls, r, s), ln = l + alpha_d * dv[ls * ROWS + r];
+                        // an accepted trial point: the true slack (>= 0 up to rounding; floored so that lam / s stays 0), zero multipliers;
+                        // an accepted polish point: the same, with the new multipliers lam_e + rho gap' on the active rows (gap' = -sn)
+                        const bool pa = was_polish && ((pmask[ls] >> r) & 1);
+                        const double lp = pa ? fmax(((s < l) ? l : 0.0) - MPCX_POLISH_RHO * sn, 0.0) : 0.0;
+                        cx.st_s(ls * ROWS + r, ((was_trial || was_polish) && row_on(ls, r)) ? fmax(sn, 1e-30) : sn);
+                        cx.st_l(ls * ROWS + r, was_trial ? 0.0 : (was_polish ? lp : ln));
                     }
             }
             MPCX_UNROLL
@@ -922,7 +1018,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 X0[ls] += alpha * E0[ls]; X1[ls] += alpha * E1[ls]; X2[ls] += alpha * E2[ls]; X3[ls] += alpha * E3[ls];
             }
             if constexpr (JERK) Z0 += alpha * DZC;
-            if (!was_trial) it++;
+            if (!was_trial && !was_polish) { it++; skip_test = false; }
         }
         cx.stamp(9);                    // [update]
     }

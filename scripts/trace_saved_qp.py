@@ -3,16 +3,23 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mpc_for_av_at_intersection_amd.runtime import Context, MpcParams
-d = np.load(sys.argv[1]); i = int(sys.argv[2]) if len(sys.argv) > 2 else 0; T = 20
+d = np.load(sys.argv[1]); i = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+pre = 's0/' if 's0/x0' in d.files else ''
+T = d[pre + 'xref'].shape[2] - 1
 ctx = Context(0); ctx.set_mpc_params(MpcParams(T=T)); ctx.set_qp_solver('stage')
 f = torch.float64
 big = torch.zeros((1 + 128, 4), dtype=f, device=ctx.device)
 out = dict(x=torch.empty((1, 4, T + 1), dtype=f, device=ctx.device), u=torch.empty((1, 2, T), dtype=f, device=ctx.device),
            status=torch.empty(1, dtype=torch.int32, device=ctx.device), iters=torch.empty(1, dtype=torch.int32, device=ctx.device), kkt=big)
-ctx.qp_solve(ctx.f64(d['x0'][i:i + 1]), ctx.f64(d['xref'][i:i + 1]), ctx.f64(d['xbar'][i:i + 1]), ctx.u8(d['re'][i:i + 1]), ctx.f64(d['uw'][i:i + 1]), out=out)
+ctx.qp_solve(ctx.f64(d[pre + 'x0'][i:i + 1]), ctx.f64(d[pre + 'xref'][i:i + 1]), ctx.f64(d[pre + 'xbar'][i:i + 1]), ctx.u8(d[pre + 're'][i:i + 1]), ctx.f64(d[pre + 'uw'][i:i + 1]), out=out)
 ctx.synchronize()
 tr = big[1:].cpu().numpy().reshape(-1, 8)
-print('status', out['status'].item(), 'iters', out['iters'].item())
-for k, r in enumerate(tr):
+print('status', out['status'].item(), 'iters', out['iters'].item(), 'kkt', big[0].cpu().numpy())
+for k, r in enumerate(tr[:24]):
     if r[6] == 0: break
     print('it %2d rd %.3e rp %.3e mu %.3e | previous step: alpha %.4f alpha_aff %.4f sigma %.3e' % (k, r[0], r[1], r[2], r[3], r[4], r[5]))
+for k, r in enumerate(tr[24:]):
+    if r[6] == 0: break
+    print('polish round: it %d try %d | active rows %d, negative multipliers %d, violated rows %d | round %d bad %d' % (r[0], r[1], r[2], r[3], r[4], r[5] % 100, r[5] >= 100))
+if 'ou' in sys.argv:
+    pass
