@@ -63,12 +63,12 @@ int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B);             // work-queue or
 #endif
 
 /* active-set polish at the end of the interior-point iteration: the rule and the constants are those of mpcx_qp_stage.h (the host
-   build of that header has no other source; oracle.c carries the same values as ORC_POLISH_*) */
+   build of that header has no other source; the tests' CPU checker carries the same values) */
 #ifndef MPCX_POLISH
 #define MPCX_POLISH 1
 #endif
 #ifndef MPCX_POLISH_MU
-#define MPCX_POLISH_MU 1e-6
+#define MPCX_POLISH_MU 1e-5
 #define MPCX_POLISH_RP 1e-6
 #define MPCX_POLISH_RD 1e-3
 #define MPCX_POLISH_RHO 1e8

@@ -388,8 +388,8 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     bool trial = feasible0 && MPCX_TRIAL_STEP != 0, accepted = false;
     // active-set polish (see MPCX_POLISH in mpcx_qp_stage.h): a pass like the trial pass, with weight rho on the rows of the active set
     // (pm0..pm3: this lane's four rows) and lam_e + rho gap as their linear term; accepted if its end point is a KKT point
-    bool polish = false, skip_test = false, pm0 = false, pm1 = false, pm2 = false, pm3 = false;
-    int ptries = 0, pend = 0;
+    bool polish = false, pol_pred = false, pm0 = false, pm1 = false, pm2 = false, pm3 = false;
+    int ptries = 0, pend = 0, ptested = -1;
 
     for (it = 0; it <= max_iter; it++) {
         // -------- H u from the PRISTINE Hessian (restore the band entries the previous iteration patched)
@@ -415,19 +415,21 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         if (accepted) { status = MPCX_QP_OPTIMAL; break; }      // the trial / polish point, with its residuals measured above for the report
         // reduced-accuracy acceptance when the iteration cannot continue (the reference accepts ECOS's OPTIMAL_INACCURATE, mpc.py:196)
         const bool loose = !trial && resn <= tol_loose && mu <= tol_loose;
-        if (!trial && !polish && !skip_test) {       // the exit tests, once per iterate
-            const bool conv = resn <= P.tol && mu <= P.tol;
-            // stagnation exit: the stationarity residual of badly conditioned instances stalls at its rounding floor while mu keeps
-            // collapsing; after 4 consecutive reduced-accuracy iterates stop before the factorisation degrades them
-            loose_run = loose ? loose_run + 1 : 0;
-            const bool stop_ok = conv || loose_run >= 4 || (it == max_iter && loose);
-            const bool stop_fail = it == max_iter && !loose;
-            const bool near = mu <= MPCX_POLISH_MU && resp_n <= MPCX_POLISH_RP && resd_n <= MPCX_POLISH_RD;
-            if (MPCX_POLISH != 0 && (near || stop_ok || stop_fail)) {
-                polish = true; ptries = 0; pend = stop_ok ? 1 : (stop_fail ? 2 : 0);
-                pm0 = val01 && s0 < l0; pm1 = val01 && s1 < l1; pm2 = val23 && s2 < l2; pm3 = val23 && s3 < l3;
-            } else if (stop_ok) { status = MPCX_QP_OPTIMAL; break; }
-            else if (stop_fail) break;
+        if (!trial && !polish) {
+            if (MPCX_POLISH != 0 && pol_pred && ptested != it) {     // the step that led here predicted a point close enough to polish
+                polish = true; ptries = 0; pend = 0;
+            } else {                                 // the exit tests, once per iterate
+                const bool conv = resn <= P.tol && mu <= P.tol;
+                // stagnation exit: the stationarity residual of badly conditioned instances stalls at its rounding floor while mu keeps
+                // collapsing; after 4 consecutive reduced-accuracy iterates stop before the factorisation degrades them
+                loose_run = loose ? loose_run + 1 : 0;
+                const bool stop_ok = conv || loose_run >= 4 || (it == max_iter && loose);
+                const bool stop_fail = it == max_iter && !loose;
+                if (MPCX_POLISH != 0 && (stop_ok || stop_fail) && ptested != it) { polish = true; ptries = 0; pend = stop_ok ? 1 : 2; }
+                else if (stop_ok) { status = MPCX_QP_OPTIMAL; break; }
+                else if (stop_fail) break;
+            }
+            if (polish) { pm0 = val01 && s0 < l0; pm1 = val01 && s1 < l1; pm2 = val23 && s2 < l2; pm3 = val23 && s3 < l3; }
         }
 
         // -------- row of M = H + G'DG: the band part (diagonal + steer tridiagonal) is written into LDS so that the row
@@ -520,10 +522,9 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         if (bad && polish) {                                    // counts as a rejected polish pass
             ptries++;
             if (ptries >= MPCX_POLISH_TRIES) {
-                polish = false;
+                polish = false; ptested = it;
                 if (pend == 1) { status = MPCX_QP_OPTIMAL; break; }
                 if (pend == 2) break;
-                skip_test = true;
             }
             it--; continue;
         }
@@ -543,8 +544,8 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         }
         // -------- predictor (affine scaling) direction
         double w0 = -m01 * t0 + d0 * rp0, w1 = -m01 * t1 + d1 * rp1, w2 = -m23 * t2 + d2 * rp2, w3 = -m23 * t3 + d3 * rp3;
-        // lam_e: the iterate's multiplier where the iterate itself holds the row active (rows that entered the set later: 0)
-        const double e0 = (s0 < l0) ? l0 : 0.0, e1 = (s1 < l1) ? l1 : 0.0, e2l = (s2 < l2) ? l2 : 0.0, e3 = (s3 < l3) ? l3 : 0.0;
+        // multiplier estimates of the augmented-Lagrangian solve: the iterate's
+        const double e0 = l0, e1 = l1, e2l = l2, e3 = l3;
         if (polish) {       // rd above carries G' lam: take it out, put the active rows' lam_e + rho gap in (gap = rp - s)
             w0 = -m01 * l0 + (pm0 ? e0 + MPCX_POLISH_RHO * (rp0 - s0) : 0.0); w1 = -m01 * l1 + (pm1 ? e1 + MPCX_POLISH_RHO * (rp1 - s1) : 0.0);
             w2 = -m23 * l2 + (pm2 ? e2l + MPCX_POLISH_RHO * (rp2 - s2) : 0.0); w3 = -m23 * l3 + (pm3 ? e3 + MPCX_POLISH_RHO * (rp3 - s3) : 0.0);
@@ -568,10 +569,9 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
                 pm0 = (pm0 || vi0) && !ng0; pm1 = (pm1 || vi1) && !ng1; pm2 = (pm2 || vi2) && !ng2; pm3 = (pm3 || vi3) && !ng3;
                 ptries++;
                 if (ptries >= MPCX_POLISH_TRIES) {
-                    polish = false;
+                    polish = false; ptested = it;       // pend == 0: the iterate now takes its exit tests and the iteration goes on
                     if (pend == 1) { status = MPCX_QP_OPTIMAL; break; }
                     if (pend == 2) break;
-                    skip_test = true;               // the iteration goes on from the iterate the exit tests have already seen
                 }
             }
             it--;                                   // not an iteration
@@ -626,19 +626,22 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
         double alpha_d = (MPCX_STEP_FRACTION < rat_d) ? MPCX_STEP_FRACTION * frcp(rat_d) : 1.0;
         // centrality safeguard (wide neighbourhood): shorten the step until min_i s_i*lam_i >= 1e-3 * mu at the new point;
         // plain Mehrotra otherwise cycles on poorly centred iterates (mu oscillates, residuals -> 0)
+        double mu_next = 0.0;
         for (int tr = 0; tr < 6; tr++) {
             const double q0 = (s0 + alpha * ds0) * (l0 + alpha_d * dl0), q1 = (s1 + alpha * ds1) * (l1 + alpha_d * dl1);
             const double q2 = (s2 + alpha * ds2) * (l2 + alpha_d * dl2), q3 = (s3 + alpha * ds3) * (l3 + alpha_d * dl3);
             const double big = 1e300;
             const double pmin = -wave_max_dpp(-fmin(fmin(val01 ? q0 : big, val01 ? q1 : big), fmin(val23 ? q2 : big, val23 ? q3 : big)));
             const double psum = wave_sum_dpp(m01 * (q0 + q1) + m23 * (q2 + q3));
+            mu_next = psum * minv;
             if (pmin >= 1e-3 * (psum * minv)) break;
             alpha *= 0.7; alpha_d *= 0.7;
         }
         u += alpha * du;
         s0 += alpha * ds0; s1 += alpha * ds1; s2 += alpha * ds2; s3 += alpha * ds3;
         l0 += alpha_d * dl0; l1 += alpha_d * dl1; l2 += alpha_d * dl2; l3 += alpha_d * dl3;
-        skip_test = false;
+        // is the new iterate close enough to polish?  (the rule of mpcx_qp_stage.h; resd_n / resp_n are relative to gnorm / hnorm)
+        pol_pred = mu_next <= MPCX_POLISH_MU && (1.0 - alpha) * resp_n <= MPCX_POLISH_RP && (1.0 - fmin(alpha, alpha_d)) * resd_n <= MPCX_POLISH_RD;
     }
     // exit residuals (absolute, for the kkt[] report)
     const double res_d = wave_max_dpp(fabs(rd));

@@ -84,7 +84,6 @@ struct QueueSrc {
                                    a.x_out + (size_t)b * 4 * W, a.u_out + (size_t)b * 2 * T, a.kkt + (size_t)b * 4,
                                    a.status + b, a.iters + b};
     }
-    __device__ __forceinline__ mpcx_stage::Problem first() const { return at(0); }
     // every round either advances some group's iteration counter or consumes a ticket
 #ifndef MPCX_REFILL_GROUPS
 #define MPCX_REFILL_GROUPS 2
@@ -92,13 +91,13 @@ struct QueueSrc {
     __device__ __forceinline__ int refill_min() const { return MPCX_REFILL_GROUPS * LQ; }   // in lanes
     __device__ __forceinline__ long max_rounds() const { return ((long)a.B + 2) * (long)(a.p.max_iter + 6) * (MPCX_POLISH_TRIES + 1); }
     template <class Cx>
-    __device__ __forceinline__ bool fetch(Cx &cx, mpcx_mpc_params &P, mpcx_stage::Problem &pb) const {
+    __device__ __forceinline__ bool fetch(Cx &cx, mpcx_mpc_params &P, int &pbi) const {
         int t = 0;
         if (cx.q == 0) t = atomicAdd(a.ticket, 1);
         t = (int)cx.gsum((double)t);                  // the other lanes contribute 0: everybody gets the leader's ticket
         const bool have = t < (a.has_queue_len ? *a.queue_len : a.B);
         const int b = have ? (a.has_order ? a.order[t] : t) : 0;
-        pb = at(b);
+        pbi = b;
         if (TUNED) {
             const mpcx_qp_tuning &tu = a.tune[b];
             P.w_perp = tu.w_perp; P.w_para = tu.w_para;

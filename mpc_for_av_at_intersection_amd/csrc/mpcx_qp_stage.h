@@ -41,12 +41,13 @@
 #ifndef MPCX_TRIAL_STEP
 #define MPCX_TRIAL_STEP 1            /* try the unconstrained minimiser before the interior-point iteration (see `trial` below) */
 #endif
-/* Active-set polish (round 3; same rule in oracle.c and in the condensed solver): an interior-point iterate sits ~sqrt(mu) from the optimum
+/* Active-set polish (round 3; same rule in the condensed solver and in the tests' CPU checker): an interior-point iterate sits ~sqrt(mu) from the optimum
    on weakly active rows, and the low curvature of the input cost (2R = 0.02) amplifies that -- up to 1e-3 on the hard closed-loop
    problems at the reduced-accuracy exit.  Once the iterate is close (mu <= MPCX_POLISH_MU with small residuals, or at any exit) the
    rows with s < lam are taken as the active set and ONE augmented-Lagrangian solve is made on it -- a round whose barrier weights
    are rho on the active rows and 0 elsewhere, with lam_a + rho gap_a as the rows' linear term: the trial pass below is the special
-   case "no active row".  The end point is accepted only if it is a KKT point (new multipliers lam_a + rho gap_a' >= 0, no other
+   case "no active row".  "Close" is decided at the END of the step that produces the iterate (the new mu is known exactly there, the
+   residuals shrink by one minus the step lengths), so that the polish round takes the place of the iterate's first row pass.  The end point is accepted only if it is a KKT point (new multipliers lam_a + rho gap_a' >= 0, no other
    row violated): then it is the minimiser up to |lam - lam*| / rho.  Otherwise rows with a negative multiplier leave the set,
    violated rows enter it, and the round is repeated, MPCX_POLISH_TRIES times in all; after that nothing is kept and the iteration goes on
    (or ends with its own iterate).  Polish rounds are not counted as iterations. */
@@ -54,7 +55,7 @@
 #define MPCX_POLISH 1
 #endif
 #ifndef MPCX_POLISH_MU
-#define MPCX_POLISH_MU 1e-6         /* entry: mu, primal residual / hnorm, dual residual / gnorm below these (or any exit) */
+#define MPCX_POLISH_MU 1e-5         /* entry: mu, primal residual / hnorm, dual residual / gnorm predicted below these (or any exit) */
 #define MPCX_POLISH_RP 1e-6
 #define MPCX_POLISH_RD 1e-3
 #define MPCX_POLISH_RHO 1e8         /* penalty of the augmented-Lagrangian solve */
@@ -86,7 +87,9 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     constexpr bool JERK = Cx::JERK;
     const int q = cx.q;
     mpcx_mpc_params P = src.params();       // weights / limits may be replaced per problem by fetch(); T, dt, L never change
-    Problem pb = src.first();
+    int pbi = 0;                            // index of the group's problem: its pointers are rebuilt where they are needed (set-up, hand-in)
+    double PH[SPL] = {};                                      // yaw of the linearisation point (for C_t)
+    double xs[4] = {0.0, 0.0, 0.0, 0.0};                      // x0
     const int T = P.T, W = T + 1;
     const double dt = P.dt;
     const double minv = 1.0 / (double)(8 * T - 2);
@@ -102,8 +105,6 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     // The reference window is read once per problem; the iterate moves by alpha * dx either way.
     double X0[SPL] = {}, X1[SPL] = {}, X2[SPL] = {}, X3[SPL] = {}, XRV[SPL] = {};
     bool act[SPL] = {}, rate[SPL] = {};
-    double PH[SPL] = {};                                      // yaw of the linearisation point (for C_t)
-    double x00 = 0.0, x01 = 0.0, x02 = 0.0, x03 = 0.0;
     double Z0 = 0.0, jw2 = 0.0;                               // JERK: the iterate of x4_0 (uniform within a group), 2 w dt^2
     double Rda = 0.0, Rds = 0.0, wv_run = 0.0, wp_run = 0.0, wv_end = 0.0, wp_end = 0.0;
     double ra_run = 1.0, rs_run = 1.0, ra_end = 1.0, rs_end = 1.0, rmax = 0.0, hnorm = 1.0, gnorm = 1.0, tol_loose = 1e-7;
@@ -118,9 +119,11 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     bool trial = false, accepted = false;
     // polish rounds (see MPCX_POLISH above): the current active set, one byte of row bits per slot; rounds tried; what the group does
     // if no round is accepted (0: the iteration goes on, 1: it ends OPTIMAL with its own iterate, 2: it ends as it is -- MAXITER)
-    bool polish = false, skip_test = false;
-    int ptries = 0, pend = 0;
-    uint8_t pmask[SPL] = {};
+    // The active set of a polishing group is kept in the SIGN of the stored slacks (an iterate's slacks are positive): a row is in the
+    // set iff the group is polishing and its stored s is negative.  Every pass takes |s| (a free source modifier) and the set costs no
+    // registers.  The signs go away with the next step (of an accepted round, or of the iteration after the group gave up).
+    bool polish = false, pinit = false;     // pinit: the set is still to be taken from the iterate (rows with s < lam)
+    int ptries = 0, pend = 0, ptested = -1; // ptested: the iterate (by its count) that has had its polish rounds
 #ifdef MPCX_STAGE_TRACE
     double trace_alpha = 0.0, trace_aff = 0.0, trace_sigma = 0.0;       // dev build: per-iteration history of one problem
     int trace_n = 0;
@@ -136,7 +139,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     // ---- serial sweeps are written as "turns": lane `turn` works on its slots, then hands its carry to the neighbour
     // forward rollout of the linear model from (u0, u1): fills (X0..X3); `free` = true uses u = 0 (free response)
     auto rollout = [&](bool free_resp, double (&Y0)[SPL], double (&Y1)[SPL], double (&Y2)[SPL], double (&Y3)[SPL]) {
-        double c0 = x00, c1 = x01, c2 = x02, c3 = x03;
+        double c0 = xs[0], c1 = xs[1], c2 = xs[2], c3 = xs[3];
         double c4 = (JERK && !free_resp) ? Z0 : 0.0;
         for (int turn = 0; turn < NTURN; turn++) {
             if (q == turn) {
@@ -248,6 +251,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     // initial point (same rules as the condensed solver).  With have == false everything is zeroed, so the group idles harmlessly.
     auto setup = [&]() {
         const bool valid = have;
+        const Problem pb = src.at(pbi);
         // every global load of the new problem is issued here, before anything waits for one (the refill is run ~16 times per
         // wavefront with all eight groups waiting for it; the reference window used to be read twice, each time behind a sweep)
         double in_vb[SPL], in_ph[SPL], in_yr[SPL], in_r0[SPL], in_r1[SPL], in_r2[SPL], in_u0[SPL], in_u1[SPL];
@@ -289,8 +293,9 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         }
         {
             const double v0 = pb.x0[0], v1 = pb.x0[1], v2 = pb.x0[2], v3 = pb.x0[3];
-            x00 = valid ? v0 : 0.0; x01 = valid ? v1 : 0.0; x02 = valid ? v2 : 0.0; x03 = valid ? v3 : 0.0;
+            xs[0] = valid ? v0 : 0.0; xs[1] = valid ? v1 : 0.0; xs[2] = valid ? v2 : 0.0; xs[3] = valid ? v3 : 0.0;
         }
+        const double x02 = xs[2];
     
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++) {
@@ -366,10 +371,11 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         running = valid && feasible0;
         trial = running && MPCX_TRIAL_STEP != 0;
         accepted = false;
-        polish = false; skip_test = false; ptries = 0; pend = 0;
+        polish = false; pinit = false; ptries = 0; pend = 0; ptested = -1;
     };
     // ------------------------------------------------------------------ a finished problem leaves: u, x = rollout of the linear model
     auto emit = [&]() {
+        const Problem pb = src.at(pbi);
         rollout(false, X0, X1, X2, X3);
         {
             MPCX_UNROLL
@@ -381,7 +387,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                     pb.x_out[2 * W + t + 1] = X2[ls]; pb.x_out[3 * W + t + 1] = X3[ls];
                 }
             if (q == 0) {
-                pb.x_out[0] = x00; pb.x_out[W] = x01; pb.x_out[2 * W] = x02; pb.x_out[3 * W] = x03;
+                pb.x_out[0] = xs[0]; pb.x_out[W] = xs[1]; pb.x_out[2 * W] = xs[2]; pb.x_out[3 * W] = xs[3];
                 *pb.status = status; *pb.iters = it;
                 pb.kkt[0] = res_d; pb.kkt[1] = res_p; pb.kkt[2] = mu; pb.kkt[3] = 0.0;
             }
@@ -393,7 +399,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
     // problem.  `cx.any` keeps the wavefront together (cross-lane operations need every lane in the loop); the loop is
     // bounded by construction: each round either advances an iteration counter or consumes a ticket.
     const long rounds = src.max_rounds();
-    have = src.fetch(cx, P, pb);            // every group draws its first problem
+    have = src.fetch(cx, P, pbi);           // every group draws its first problem
     drained = !have;
     setup();
     for (long guard = 0; guard < rounds; guard++) {
@@ -407,7 +413,17 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         // refill sat in front of the residual pass, and every problem paid one whole round just to be told it had converged.)
         MPCX_NOUNROLL
         for (int pass = 0; pass < 2; pass++) {
+            if (cx.any(pinit)) {            // groups that start polishing at an exit mark the rows their iterate holds active (rare: the usual
+                MPCX_NOUNROLL               // entry is decided by the step, which writes the marks itself; rows that are off hold s = 1, lam = 0)
+                for (int k = 0; k < SPL * ROWS; k++) {
+                    const double sk = fabs(cx.ld_s(k)), lk = cx.ld_l(k);
+                    if (pinit) cx.st_s(k, sk < lk ? -sk : sk);
+                }
+                pinit = false;
+                cx.fence();
+            }
             // ---- local pass A: rows, complementarity, gradient pieces
+            const bool ipm = !(trial || polish);
             prev_of(U1, Dprev);
             double L45[SPL], N45[SPL];                    // (lam4 - lam5), (nu4 - nu5) of the predictor
             double QL2[SPL], QA2[SPL], RL0[SPL], RL1[SPL], RA0[SPL], RA1[SPL];
@@ -420,18 +436,21 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 MPCX_UNROLL
                 for (int r = 0; r < ROWS; r++) {
                     const bool on = row_on(ls, r);
-                    const double s = sv[r], l = trial ? 0.0 : lv[r];
+                    // A polish round puts weight rho on the rows of the active set, with lam + rho gap as their linear term (lam = the
+                    // iterate's multiplier), and nothing on the other rows (a trial round has no active row at all).  That is what the
+                    // iteration's own formulas d = lam / s, nu = d (s + gap) give for a row with the slack lam / rho -- so an active
+                    // row is an ordinary row with that slack, an inactive one a row with a zero multiplier, and no pass below has polish
+                    // arithmetic of its own.
+                    const bool pa = polish & (sv[r] < 0.0);  // the row is in a polishing group's active set (bitwise: a lane-varying && / || compiles to a branch per row)
+                    const double s = pa ? lv[r] * (1.0 / MPCX_POLISH_RHO) : fabs(sv[r]);
+                    const double l = (pa | (on & ipm)) ? lv[r] : 0.0;
                     const double is = cx.rcp(s);
-                    const double gap = row_gap(ls, r, Dprev[ls]);
-                    const double rp = on ? s + gap : 0.0;
-                    // a polish round: weight rho on the rows of the active set, their linear term lam_e + rho gap (lam_e = the
-                    // iterate's multiplier where the iterate itself had the row active, 0 for rows that entered later)
-                    const bool pa = polish && ((pmask[ls] >> r) & 1);
-                    const double d = polish ? (pa ? MPCX_POLISH_RHO : 0.0) : (on ? l * is : 0.0);
+                    const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
+                    const double d = l * is;
                     dd[r] = d;
-                    lam[r] = on ? l : 0.0;
-                    nu[r] = polish ? (pa ? ((s < l) ? l : 0.0) + MPCX_POLISH_RHO * gap : 0.0) : d * rp;
-                    mu_s += on ? s * l : 0.0;
+                    lam[r] = l;
+                    nu[r] = d * rp;
+                    mu_s += s * l;
                     rp_m = fmax(rp_m, fabs(rp));
                 }
                 DSa[ls] = dd[0] + dd[1]; DSd[ls] = dd[2] + dd[3]; DSr[ls] = dd[4] + dd[5]; DSv[ls] = dd[6] + dd[7];
@@ -467,40 +486,26 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             const double n_rd = cx.gmax(rd_m), n_rp = cx.gmax(rp_m);
             n_mu = cx.gsum(mu_s) * minv;
             if (running && !polish) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
-            const bool test = running && !trial && !polish && !skip_test && (pass == 0 || fresh);      // a group takes the exit tests once per iterate
+            const bool test = running && !trial && !polish && (pass == 0 || fresh);      // a group takes the exit tests once per iterate
             if (test && accepted) { status = MPCX_QP_OPTIMAL; running = false; }     // residuals of the accepted trial point: measured above, for the report
 #ifdef MPCX_STAGE_TRACE
             if (test) cx.trace(it, res_d, res_p, mu, trace_alpha, trace_aff, trace_sigma);
 #endif
             cx.stamp(2);                    // [costate sweep]
             // ---- exit tests (uniform per group)
-            bool entered = false;           // the group starts polishing in this round: its row pass has to be redone with the polish weights
-            {
-                // the rows the iterate holds active (s < lam), in case the group starts polishing (loads unconditional, see rows_of)
-                uint8_t am[SPL];
-                MPCX_UNROLL
-                for (int ls = 0; ls < SPL; ls++) {
-                    double sv[ROWS], lv[ROWS];
-                    rows_of(ls, sv, lv);
-                    unsigned m8 = 0;
-                    MPCX_UNROLL
-                    for (int r = 0; r < ROWS; r++) m8 |= (row_on(ls, r) && sv[r] < lv[r]) ? (1u << r) : 0u;
-                    am[ls] = (uint8_t)m8;
-                }
-                if (test && running) {
-                    const bool conv = res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol;
-                    loose = (res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose);
-                    loose_run = loose ? loose_run + 1 : 0;
-                    const bool stop_ok = conv || loose_run >= 4 || (it == max_iter && loose);
-                    const bool stop_fail = it == max_iter && !loose;
-                    const bool near = mu <= MPCX_POLISH_MU && res_p <= MPCX_POLISH_RP * hnorm && res_d <= MPCX_POLISH_RD * gnorm;
-                    if (MPCX_POLISH != 0 && (near || stop_ok || stop_fail)) {
-                        polish = true; entered = true; ptries = 0; pend = stop_ok ? 1 : (stop_fail ? 2 : 0);
-                        MPCX_UNROLL
-                        for (int ls = 0; ls < SPL; ls++) pmask[ls] = am[ls];
-                    } else if (stop_ok) { status = MPCX_QP_OPTIMAL; running = false; }
-                    else if (stop_fail) running = false;
-                }
+            // a group that reaches an exit without having polished this iterate polishes it now: its row pass is redone with the polish
+            // weights (rare: the usual entry is decided at the end of the step, see below)
+            bool entered = false;
+            if (test && running) {
+                const bool conv = res_d <= P.tol * gnorm && res_p <= P.tol * hnorm && mu <= P.tol;
+                loose = (res_d <= tol_loose * gnorm && res_p <= tol_loose * hnorm && mu <= tol_loose);
+                loose_run = loose ? loose_run + 1 : 0;
+                const bool stop_ok = conv || loose_run >= 4 || (it == max_iter && loose);
+                const bool stop_fail = it == max_iter && !loose;
+                if (MPCX_POLISH != 0 && (stop_ok || stop_fail) && ptested != it) {
+                    polish = true; pinit = true; entered = true; ptries = 0; pend = stop_ok ? 1 : 2;
+                } else if (stop_ok) { status = MPCX_QP_OPTIMAL; running = false; }
+                else if (stop_fail) running = false;
             }
             if (pass == 1) break;
             // hand-in / draw / set-up costs the whole wavefront a few thousand instructions: do it when at least `refill_min`
@@ -510,7 +515,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             fresh = false;
             if (need) {                  // uniform within a group: the DPP operations inside stay inside the group
                 if (have) emit();
-                have = src.fetch(cx, P, pb);
+                have = src.fetch(cx, P, pbi);
                 drained = !have;         // the queue is empty: zero the group's data once and idle from now on
                 setup();
                 fresh = true;
@@ -778,8 +783,9 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         cx.stamp(4);                    // [forward sweep 1]
         prev_of(DA1, DAp);
         double al = 1.0, c1 = 0.0, c2 = 0.0;
-        bool viol = false;              // trial: a row is violated at the predictor's end point
-        uint8_t pneg[SPL] = {}, pvio[SPL] = {};     // polish: active rows whose new multiplier is negative / other rows violated at the end point
+        bool viol = false;              // trial / polish: the predictor's end point is no KKT point (a row violated, a multiplier negative)
+        const bool ipm = !(trial || polish);
+        const double veps = trial ? 0.0 : MPCX_POLISH_EPS_G;
         // per row, recomputed from (s, lam, u, x) wherever needed instead of being kept: rp = s + gap, d = lam / s
         MPCX_UNROLL
         for (int ls = 0; ls < SPL; ls++) {
@@ -788,19 +794,20 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             MPCX_UNROLL
             for (int r = 0; r < ROWS; r++) {
                 const bool on = row_on(ls, r);
-                const double s = sv[r], l = (on && !trial) ? lv[r] : 0.0;
+                const bool pa = polish & (sv[r] < 0.0);
+                const double sa = fabs(sv[r]);
+                const double s = pa ? lv[r] * (1.0 / MPCX_POLISH_RHO) : sa;
+                const double l = (pa | (on & ipm)) ? lv[r] : 0.0;
                 const double gap = row_gap(ls, r, Dprev[ls]), dir = row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]);
                 const double rp = on ? s + gap : 0.0;
                 const double d = l * cx.rcp(s);
                 const double dsa = on ? -rp - dir : 0.0;
                 const double dla = -l - d * dsa;
-                viol = viol || (on && !(gap + dir <= 0.0));
-                {
-                    const bool pa = (pmask[ls] >> r) & 1;
-                    const double ln = ((s < l) ? l : 0.0) + MPCX_POLISH_RHO * (gap + dir);
-                    pneg[ls] |= (pa && ln < -MPCX_POLISH_EPS_L) ? (1u << r) : 0u;
-                    pvio[ls] |= (!pa && on && gap + dir > MPCX_POLISH_EPS_G) ? (1u << r) : 0u;
-                }
+                // the end point of a trial / polish round: rows outside the active set must hold, the new multipliers of the rows inside it
+                // (lam + dla = lam + rho gap') must not be negative
+                const bool o_in = l + dla < -MPCX_POLISH_EPS_L, o_out = !(gap + dir <= veps);      // (both evaluated: no branch per row)
+                viol = viol | (pa & o_in) | (!pa & on & o_out);
+                (void)sa;
                 // ratio tests: any value <= the exact ratio is a valid step bound, the 0.001 margin of MPCX_STEP_FRACTION is 12 orders above rcp_fast's error
                 al = fmin(al, (on && dsa < 0.0) ? -s * cx.rcp_fast(dsa) : 1.0);
                 al = fmin(al, (on && dla < 0.0) ? -l * cx.rcp_fast(dla) : 1.0);
@@ -821,30 +828,40 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         // group gives up polishing -- the iterate has not been touched
         const bool was_polish = polish;
         if (polish) {
-            bool ch = false;
-            MPCX_UNROLL
-            for (int ls = 0; ls < SPL; ls++) ch = ch || pneg[ls] != 0 || pvio[ls] != 0;
-            const bool rej = cx.gany(ch) || any_bad;
+            const bool rej = cx.gany(viol) || any_bad;
             accepted = running && !rej;
 #ifdef MPCX_STAGE_TRACE
-            {
-                double na = 0.0, nn = 0.0, nv = 0.0;
-                MPCX_UNROLL
-                for (int ls = 0; ls < SPL; ls++) { na += __builtin_popcount(pmask[ls]); nn += __builtin_popcount(pneg[ls]); nv += __builtin_popcount(pvio[ls]); }
-                cx.trace(24 + trace_n++, (double)it, (double)ptries, cx.gsum(na), cx.gsum(nn), cx.gsum(nv), (any_bad ? 100.0 : 0.0) + (double)guard);
-            }
+            cx.trace(24 + trace_n++, (double)it, (double)ptries, rej ? 1.0 : 0.0, 0.0, 0.0, (any_bad ? 100.0 : 0.0) + (double)guard);
 #endif
-            if (rej) {
-                if (!any_bad) {
-                    MPCX_UNROLL
-                    for (int ls = 0; ls < SPL; ls++) pmask[ls] = (uint8_t)((pmask[ls] | pvio[ls]) & ~pneg[ls]);
+            if (cx.any(rej && !any_bad && ptries + 1 < MPCX_POLISH_TRIES)) {
+                // rare: the active set of the next polish round -- rows with a negative multiplier leave, violated rows enter.  Rolled loop
+                // over the rows of a slot: small code, few registers.
+                const bool fix = rej && !any_bad;
+                MPCX_UNROLL
+                for (int ls = 0; ls < SPL; ls++) {
+                    MPCX_NOUNROLL
+                    for (int r = 0; r < ROWS; r++) {
+                        const double sr = cx.ld_s(ls * ROWS + r), lr = cx.ld_l(ls * ROWS + r);
+                        const bool on = row_on(ls, r);
+                        const bool pa = sr < 0.0;
+                        const double sa = fabs(sr);
+                        const double s = pa ? lr * (1.0 / MPCX_POLISH_RHO) : sa;
+                        const double l = pa ? lr : 0.0;
+                        const double gd = row_gap(ls, r, Dprev[ls]) + row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]);
+                        const double dsa = on ? -(s + gd) : 0.0;
+                        const double dla = -l - (l * cx.rcp(s)) * dsa;
+                        const bool out = pa ? (l + dla < -MPCX_POLISH_EPS_L) : (on && !(gd <= MPCX_POLISH_EPS_G));
+                        if (fix) cx.st_s(ls * ROWS + r, (pa != out) ? -sa : sa);
+                    }
                 }
+                cx.fence();
+            }
+            if (rej) {
                 ptries++;
                 if (ptries >= MPCX_POLISH_TRIES) {
-                    polish = false;
+                    polish = false; ptested = it;       // pend == 0: the iterate takes its exit tests in the next round and the iteration goes on
                     if (pend == 1) { status = MPCX_QP_OPTIMAL; running = false; }
                     else if (pend == 2) running = false;
-                    else skip_test = true;              // the iteration goes on from the iterate the exit tests have already seen
                 }
             } else polish = false;
         }
@@ -876,16 +893,20 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 MPCX_UNROLL
                 for (int r = 0; r < ROWS; r++) {
                     const bool on = row_on(ls, r);
-                    const double s = sv[r], l = (on && !was_trial) ? lv[r] : 0.0;
+                    const bool pa = was_polish & (sv[r] < 0.0);
+                    const bool full = on & !was_trial & !was_polish;             // a row of an ordinary iteration
+                    const double s = pa ? lv[r] * (1.0 / MPCX_POLISH_RHO) : fabs(sv[r]);
+                    const double l = (pa | full) ? lv[r] : 0.0;
                     const double is = cx.rcp(s);
                     const double rp = on ? s + row_gap(ls, r, Dprev[ls]) : 0.0;
                     const double dsa = on ? -rp - row_dir(r, DA0[ls], DA1[ls], DAp[ls], EA2[ls]) : 0.0;
                     const double dla = -l - (l * is) * dsa;
-                    const double rc = (on && !was_trial && !was_polish) ? s * l + alpha_aff * (dsa * dla) - smu : 0.0;
+                    // a trial / polish round has no corrector (no second-order term, no centring): its right-hand side is the predictor's
+                    // again, the second forward sweep repeats the first, and the step below -- at full length, if the round was accepted --
+                    // IS the move to the end point that was checked
+                    const double rc = s * l + (full ? alpha_aff * (dsa * dla) - smu : 0.0);
                     RC[ls][r] = rc * is;                                         // rc / s
-                    const bool pa = was_polish && ((pmask[ls] >> r) & 1);       // an accepted polish round keeps its mask: same linear terms as its predictor
-                    nu[r] = was_polish ? (pa ? ((s < l) ? l : 0.0) + MPCX_POLISH_RHO * row_gap(ls, r, Dprev[ls]) : 0.0)
-                                       : (on ? l + (l * rp) * is - rc * is : 0.0);
+                    nu[r] = l + (l * rp) * is - rc * is;
                 }
                 C01[ls] = nu[0] - nu[1]; C23[ls] = nu[2] - nu[3]; C45[ls] = nu[4] - nu[5]; C67[ls] = nu[6] - nu[7];
             }
@@ -950,9 +971,14 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             MPCX_UNROLL
             for (int r = 0; r < ROWS; r++) {
                 const bool on = row_on(ls, r);
-                const double s = sv[r], l = (on && !was_trial) ? lv[r] : 0.0;
+                const bool pa = was_polish & (sv[r] < 0.0);
+                const bool full = on & !was_trial & !was_polish;
+                const double s = pa ? lv[r] * (1.0 / MPCX_POLISH_RHO) : fabs(sv[r]);
+                const double l = (pa | full) ? lv[r] : 0.0;
                 const double ds = slack_step(ls, r, s);
-                const double dl = on ? -RC[ls][r] - (l * cx.rcp(s)) * ds : 0.0;
+                // the multiplier step; in a trial / polish round the rows outside the active set end with a zero multiplier (written as a
+                // step from the stored one, so that the update below has no special case), the rows inside it with lam + rho gap'
+                const double dl = (pa | full) ? -RC[ls][r] - (l * cx.rcp(s)) * ds : -lv[r];
                 cx.st_k(ls * ROWS + r, dl);
                 am_p = fmin(am_p, (on && ds < 0.0) ? -s * cx.rcp_fast(ds) : 1e300);
                 am_d = fmin(am_d, (on && dl < 0.0) ? -l * cx.rcp_fast(dl) : 1e300);
@@ -966,6 +992,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         if (alpha > 1.0 || was_trial || was_polish) alpha = 1.0;
         if (alpha_d > 1.0 || was_trial || was_polish) alpha_d = 1.0;
         // centrality safeguard: shorten until min s*lam >= 1e-3 * mean at the new point (at most 6 times)
+        double mu_next = 0.0;           // mu at the point the step leads to (of the last evaluation: exact unless the step was shortened after it)
         for (int tr = 0; tr < 6; tr++) {
             double pmin = 1e300, psum = 0.0;
             MPCX_UNROLL
@@ -977,12 +1004,13 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 MPCX_UNROLL
                 for (int r = 0; r < ROWS; r++) {
                     const bool on = row_on(ls, r);
-                    const double s = sv[r], l = lv[r];
+                    const double s = fabs(sv[r]), l = lv[r];
                     const double pr = (s + alpha * slack_step(ls, r, s)) * (l + alpha_d * dv[r]);
                     pmin = fmin(pmin, on ? pr : 1e300); psum += on ? pr : 0.0;
                 }
             }
             const double gmn = cx.gmin(pmin), gsm = cx.gsum(psum);
+            mu_next = gsm * minv;
             const bool ok = gmn >= 1e-3 * (gsm * minv);
             if (!cx.any(running && !was_trial && !was_polish && !ok)) break;
             if (!ok && !was_trial && !was_polish) { alpha *= 0.7; alpha_d *= 0.7; }      // (a trial / polish group takes the full step or none)
@@ -993,6 +1021,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         cx.stamp(8);                    // [local pass E + safeguard]
         // ---- step
         if (running && (!(was_trial || was_polish) || accepted)) {
+            // is the new iterate close enough to polish?  (same rule in the condensed solver: mu of the new point, the primal residual shrinks by
+            // 1 - alpha, the dual one by about the smaller of the two step lengths.)  If so the group polishes from the next round on,
+            // and the step itself marks the rows the new iterate holds active (s < lam) by the sign of the stored slack.
+            const bool pnext = MPCX_POLISH != 0 && !was_trial && !was_polish && mu_next <= MPCX_POLISH_MU &&
+                               (1.0 - alpha) * res_p <= MPCX_POLISH_RP * hnorm &&
+                               (1.0 - (alpha < alpha_d ? alpha : alpha_d)) * res_d <= MPCX_POLISH_RD * gnorm;
             {
                 double sv[SPL * ROWS], lv[SPL * ROWS], dv[SPL * ROWS];       // every load in flight before the first store
                 MPCX_UNROLL
@@ -1001,15 +1035,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 for (int ls = 0; ls < SPL; ls++)
                     MPCX_UNROLL
                     for (int r = 0; r < ROWS; r++) {          // rows that are off have ds = dl = 0
-                        const double s = sv[ls * ROWS + r];
-                        const double l = lv[ls * ROWS + r];
-                        const double sn = s + alpha * slack_step(ls, r, s), ln = l + alpha_d * dv[ls * ROWS + r];
-                        // an accepted trial point: the true slack (>= 0 up to rounding; floored so that lam / s stays 0), zero multipliers;
-                        // an accepted polish point: the same, with the new multipliers lam_e + rho gap' on the active rows (gap' = -sn)
-                        const bool pa = was_polish && ((pmask[ls] >> r) & 1);
-                        const double lp = pa ? fmax(((s < l) ? l : 0.0) - MPCX_POLISH_RHO * sn, 0.0) : 0.0;
-                        cx.st_s(ls * ROWS + r, ((was_trial || was_polish) && row_on(ls, r)) ? fmax(sn, 1e-30) : sn);
-                        cx.st_l(ls * ROWS + r, was_trial ? 0.0 : (was_polish ? lp : ln));
+                        const double s = fabs(sv[ls * ROWS + r]);
+                        const double sn = s + alpha * slack_step(ls, r, s), ln = lv[ls * ROWS + r] + alpha_d * dv[ls * ROWS + r];
+                        // an accepted trial / polish point: the true slack (>= 0 up to rounding; floored so that lam / s stays finite)
+                        const double sw = ((was_trial | was_polish) & row_on(ls, r)) ? fmax(sn, 1e-30) : sn;
+                        cx.st_s(ls * ROWS + r, (pnext & (sn < ln)) ? -sw : sw);
+                        cx.st_l(ls * ROWS + r, ln);
                     }
             }
             MPCX_UNROLL
@@ -1018,7 +1049,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                 X0[ls] += alpha * E0[ls]; X1[ls] += alpha * E1[ls]; X2[ls] += alpha * E2[ls]; X3[ls] += alpha * E3[ls];
             }
             if constexpr (JERK) Z0 += alpha * DZC;
-            if (!was_trial && !was_polish) { it++; skip_test = false; }
+            if (!was_trial && !was_polish) it++;
+            if (pnext) { polish = true; ptries = 0; pend = 0; }
         }
         cx.stamp(9);                    // [update]
     }

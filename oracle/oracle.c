@@ -263,16 +263,18 @@ static void chol_solve(const double *Lm, int n, double *b) {
 /* Active-set polish (round 3; same rule in both HIP solvers).  An interior-point iterate sits ~sqrt(mu) away from the optimum on
  * weakly active rows (s ~ lam ~ sqrt(mu)), and the low curvature of the input cost (2R = 0.02) amplifies that: on the hard
  * closed-loop problems the iteration's answer was up to 1e-3 from the exact minimiser at its reduced-accuracy exit, 5e-5 at
- * mu = 1e-10.  Once the iterate is close (mu <= ORC_POLISH_MU, or at any exit) the rows with s < lam are taken as the active
+ * mu = 1e-10.  Once the iterate is close (see `pol_pred` in orc_ipm_dense: the step that produced it predicted mu <= ORC_POLISH_MU and
+ * small residuals -- decided at the end of the step so that the HIP solvers can run the polish round in place of the iterate's
+ * first row pass), or at any exit, the rows with s < lam are taken as the active
  * set and ONE augmented-Lagrangian solve is made on it: (H + rho Ga'Ga) du = -(H u + g + Ga'(lam_a + rho gap_a)), new multipliers
  * lam_a + rho (gap_a + Ga du).  The point is accepted only if it is a KKT point: multipliers >= 0 on the active rows, no other
  * row violated; then it is the minimiser up to |lam - lam*| / rho.  Otherwise rows with a negative multiplier leave the set, violated
- * rows enter it (with a zero estimate) and the solve is repeated, ORC_POLISH_TRIES times in all; if none is accepted nothing is
+ * rows enter it and the solve is repeated, ORC_POLISH_TRIES times in all; if none is accepted nothing is
  * kept and the iteration goes on (or ends with its own iterate).  A polish solve is not counted as an iteration. */
 #ifndef ORC_POLISH
 #define ORC_POLISH 1
 #endif
-#define ORC_POLISH_MU 1e-6
+#define ORC_POLISH_MU 1e-5
 #define ORC_POLISH_RP 1e-6
 #define ORC_POLISH_RD 1e-3
 #define ORC_POLISH_RHO 1e8
@@ -283,9 +285,9 @@ static void chol_solve(const double *Lm, int n, double *b) {
 /* returns 1 and overwrites (u, s, lam) if a KKT point was found; M (n x n), du (n), w (m), gapn (m) are scratch */
 static int polish(int32_t n, int32_t m, const double *H, const double *g, const double *G, const double *h,
                   double *u, double *s, double *lam, double *M, double *du, double *w, double *gapn) {
-    unsigned char *act = malloc(m), *act0 = malloc(m);
+    unsigned char *act = malloc(m);
     int ok = 0;
-    for (int i = 0; i < m; i++) act0[i] = act[i] = s[i] < lam[i];
+    for (int i = 0; i < m; i++) act[i] = s[i] < lam[i];
     for (int tr = 0; tr < ORC_POLISH_TRIES && !ok; tr++) {
         memcpy(M, H, sizeof(double) * n * n);
         for (int i = 0; i < m; i++) {
@@ -293,7 +295,7 @@ static int polish(int32_t n, int32_t m, const double *H, const double *g, const 
             const double *Gi = G + (size_t)i * n;
             for (int k = 0; k < n; k++) gap += Gi[k] * u[k];
             gapn[i] = gap;
-            w[i] = act[i] ? ((act0[i] ? lam[i] : 0.0) + ORC_POLISH_RHO * gap) : 0.0;
+            w[i] = act[i] ? (lam[i] + ORC_POLISH_RHO * gap) : 0.0;
             if (!act[i]) continue;
             for (int a = 0; a < n; a++) {
                 if (Gi[a] == 0.0) continue;
@@ -314,7 +316,7 @@ static int polish(int32_t n, int32_t m, const double *H, const double *g, const 
             double gd = 0; for (int k = 0; k < n; k++) gd += G[i * n + k] * du[k];
             gapn[i] += gd;
             if (act[i]) {
-                w[i] = (act0[i] ? lam[i] : 0.0) + ORC_POLISH_RHO * gapn[i];      /* the new multiplier */
+                w[i] = lam[i] + ORC_POLISH_RHO * gapn[i];      /* the new multiplier */
                 if (w[i] < -ORC_POLISH_EPS_L) { change = 1; w[i] = -1.0; }       /* marks the row for removal */
             } else if (gapn[i] > ORC_POLISH_EPS_G) { change = 1; w[i] = 1.0; }  /* marks the row for entry */
             else w[i] = 0.0;
@@ -332,7 +334,7 @@ static int polish(int32_t n, int32_t m, const double *H, const double *g, const 
             s[i] = -gapn[i] > 0.0 ? -gapn[i] : 0.0;
         }
     }
-    free(act); free(act0);
+    free(act);
     return ok;
 }
 
@@ -352,7 +354,7 @@ int32_t orc_ipm_dense(const orc_mpc_params *p, int32_t n, int32_t m, const doubl
     int32_t status = ORC_MAXITER, it = 0;
     double res_d = 0, res_p = 0, mu = 0;
     const double tol_loose = p->tol > 1e-7 ? p->tol : 1e-7;
-    int loose = 0, loose_run = 0;
+    int loose = 0, loose_run = 0, pol_pred = 0;
     for (int i = 0; i < m; i++) {
         double gi = 0; for (int k = 0; k < n; k++) gi += G[i * n + k] * u[k];
         double si = h[i] - gi;
@@ -412,7 +414,7 @@ int32_t orc_ipm_dense(const orc_mpc_params *p, int32_t n, int32_t m, const doubl
         loose_run = loose ? loose_run + 1 : 0;
         const int stop = conv || loose_run >= 4 || it == p->max_iter;
         /* active-set polish: at every exit, and as soon as the iterate is close enough for the rows with s < lam to be the active set */
-        if (ORC_POLISH && (stop || (mu <= ORC_POLISH_MU && res_p <= ORC_POLISH_RP * hnorm && res_d <= ORC_POLISH_RD * gnorm))
+        if (ORC_POLISH && (stop || pol_pred)
             && polish(n, m, H, g, G, h, u, s, lam, M, du, w, dsa)) {
             status = ORC_OK; mu = 0.0;
             for (int i = 0; i < m; i++) mu += s[i] * lam[i];
@@ -478,8 +480,10 @@ int32_t orc_ipm_dense(const orc_mpc_params *p, int32_t n, int32_t m, const doubl
         if (alpha_d > 1.0) alpha_d = 1.0;
         /* centrality safeguard (wide neighbourhood): shorten the step until min_i s_i*lam_i >= 1e-3 * mu at the new point;
          * plain Mehrotra otherwise cycles on poorly centred iterates (mu oscillates, residuals -> 0) */
+        double psum = 0.0;
         for (int tr = 0; tr < 6; tr++) {
-            double pmin = 1e300, psum = 0.0;
+            double pmin = 1e300;
+            psum = 0.0;
             for (int i = 0; i < m; i++) {
                 double pr = (s[i] + alpha_p * ds[i]) * (lam[i] + alpha_d * dl[i]);
                 if (pr < pmin) pmin = pr;
@@ -487,6 +491,12 @@ int32_t orc_ipm_dense(const orc_mpc_params *p, int32_t n, int32_t m, const doubl
             }
             if (pmin >= 1e-3 * (psum / m)) break;
             alpha_p *= 0.7; alpha_d *= 0.7;
+        }
+        /* is the next iterate close enough to polish?  mu of the new point is psum / m (exactly, while the step was not shortened after
+         * the last evaluation); the primal residual shrinks by 1 - alpha_p, the dual one by about the smaller of the two steps */
+        {
+            double keep = 1.0 - (alpha_p < alpha_d ? alpha_p : alpha_d);
+            pol_pred = psum / m <= ORC_POLISH_MU && (1.0 - alpha_p) * res_p <= ORC_POLISH_RP * hnorm && keep * res_d <= ORC_POLISH_RD * gnorm;
         }
         for (int k = 0; k < n; k++) u[k] += alpha_p * du[k];
         for (int i = 0; i < m; i++) { s[i] += alpha_p * ds[i]; lam[i] += alpha_d * dl[i]; }

@@ -26,3 +26,4 @@ it = out['iters'].float().mean().item()
 print('T=%d mean iters %.2f; shader-clock ticks summed over wavefronts: %.3g' % (T, it, tot))
 for n, v in zip(names, prof):
     print('  %-28s %5.1f %%' % (n, 100 * v / tot))
+print('relative to the Riccati sweep (unchanged code: a round counter):', ' '.join('%.3f' % (v / prof[3]) for v in prof), ' sum %.3f' % (tot / prof[3]))

@@ -136,6 +136,9 @@ def exact_solution(p, x0, xref, xbar, reaches_end, z_start, max_rounds=60):
         Ga, ha, ma = G[a], h[a], len(a)
         K = np.zeros((n + me + ma, n + me + ma))
         K[:n, :n] = 2 * P; K[:n, n:n + me] = Aeq.T; K[:n, n + me:] = Ga.T; K[n:n + me, :n] = Aeq; K[n + me:, :n] = Ga
+        # a vanishing dual regularisation keeps the system solvable on a degenerate vertex (linearly dependent active rows: the multipliers
+        # are then shared out among them); it relaxes an active row by 1e-14 * lam
+        K[n + me:, n + me:] = -1e-14 * np.eye(ma)
         s = np.linalg.solve(K, np.concatenate([-q, beq, ha]))
         z, nu, lam = s[:n], s[n:n + me], s[n + me:]
         slack = h - G @ z

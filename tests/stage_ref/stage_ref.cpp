@@ -44,11 +44,11 @@ struct HostSrc {            // a queue of exactly one problem
     mpcx_stage::Problem pb;
     int taken = 0;
     mpcx_mpc_params params() const { return *p; }
-    mpcx_stage::Problem first() const { return pb; }
+    mpcx_stage::Problem at(int) const { return pb; }
     long max_rounds() const { return (long)(p->max_iter + 6) * (MPCX_POLISH_TRIES + 1); }
     int refill_min() const { return 1; }
     template <class Cx>
-    bool fetch(Cx &, mpcx_mpc_params &, mpcx_stage::Problem &out) { out = pb; return taken++ == 0; }
+    bool fetch(Cx &, mpcx_mpc_params &, int &idx) { idx = 0; return taken++ == 0; }
 };
 }  // namespace
 

@@ -1,0 +1,91 @@
+"""Accuracy of the QP solve AT SCALE: both HIP solvers against the exact minimiser of the literal problem of main/lib/mpc.py:138-208
+(tests/qp_literal.exact_solution: active-set KKT solve in numpy, no code shared with oracle.c or the kernels) on QPs harvested from
+the benchmark's own closed loop -- every >= 10-iteration problem of the start-up and steady-state windows plus a random sample, 4096
+in all -- and on the golden cold starts at T = 10 / 13 / 20.
+
+Round 2 measured this distance on 180 problems only, and the interior-point iterate turned out to sit up to 1e-3 from the optimum on
+the hard closed-loop problems (weakly active rows: s ~ lam ~ sqrt(mu), amplified by the low curvature 2R = 0.02 of the input cost).
+Round 3's active-set polish (csrc/mpcx_qp_stage.h: MPCX_POLISH) ends every constrained solve on a verified KKT point instead.
+Bar: max < 5e-6 (the north star allows 1e-4 against the reference's optimum; VERDICT r2 asked for < 5e-5)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+BAR = 5e-6
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from mpc_for_av_at_intersection_amd.runtime import Context
+    from mpc_for_av_at_intersection_amd.lib import _session
+    c = Context(0)
+    yield c
+    if _session._ctx is c:          # synthetic_batch() made this context the drop-in classes' session context: do not leave a closed one behind
+        _session.set_context(None)
+    c.close()
+
+
+def _distances(ctx, T, x0, xref, xbar, re, uw, solvers=('condensed', 'stage')):
+    """{solver: |z_gpu - z_exact| per problem}, plus the iteration counts of the last solver"""
+    from mpc_for_av_at_intersection_amd.runtime import MpcParams
+    from oracle import oracle_py as orc
+    from tests import qp_literal as QL
+    ctx.set_mpc_params(MpcParams(T=T))
+    po = orc.MpcParams(T=T)
+    res, exact = {}, [None] * len(x0)
+    for name in solvers:
+        ctx.set_qp_solver(name)
+        try:
+            out = ctx.qp_solve(ctx.f64(x0), ctx.f64(xref), ctx.f64(xbar), ctx.u8(re), None if uw is None else ctx.f64(uw))
+            ctx.synchronize()
+        finally:
+            ctx.set_qp_solver('auto')
+        assert (out['status'].cpu().numpy() == 0).all()
+        u, x, it = out['u'].cpu().numpy(), out['x'].cpu().numpy(), out['iters'].cpu().numpy()
+        dist = np.empty(len(x0))
+        for k in range(len(x0)):
+            z = QL.pack(po, x[k], u[k])
+            if exact[k] is None:
+                ex = QL.exact_solution(po, x0[k], xref[k], xbar[k], re[k], z)
+                assert ex['eq'] < 1e-9 and (ex['lam'] >= -1e-7).all() and ex['slack'].min() > -1e-9, k
+                exact[k] = ex['z']
+            dist[k] = np.abs(z - exact[k]).max()
+        res[name] = dist
+    return res, it
+
+
+def test_closed_loop_corpus_vs_exact_minimiser(ctx):
+    """>= 4096 QPs out of the benchmark's closed loop (4096 instances x 8 agents, T = 20): steps 3-8 and 100-105, every problem
+    with >= 10 interior-point iterations plus a random sample of the rest"""
+    c = H.harvest_closed_loop_qps(ctx, total=4096, hard_iters=10)
+    n_hard = int((c['iters'] >= 10).sum())
+    assert len(c['iters']) >= 4096 and n_hard >= 200, (len(c['iters']), n_hard)
+    res, it = _distances(ctx, 20, c['x0'], c['xref'], c['xbar'], c['re'], c['uw'])
+    for name, d in res.items():
+        print('%s: %d problems (%d with >= 10 iterations in the closed loop; up to %d): |z_gpu - z_exact| max %.2e  p99 %.2e  median %.2e'
+              % (name, len(d), n_hard, c['iters'].max(), d.max(), np.quantile(d, .99), np.median(d)))
+        assert d.max() < BAR, (name, d.max(), int(d.argmax()))
+        assert np.median(d) < 1e-8
+
+
+@pytest.mark.parametrize('T', [10, 13, 20])
+def test_golden_cold_starts_vs_exact_minimiser(ctx, T):
+    """the 60 golden problems per horizon (cold starts: the hardest kind, 10-17 iterations), both solvers"""
+    g = H.gold('mpc_pre.npz')
+    res, it = _distances(ctx, T, g['T%d/state' % T], g['T%d/xref' % T], g['T%d/xbar' % T], g['T%d/reaches_end' % T], None)
+    for name, d in res.items():
+        print('T=%d %s: |z_gpu - z_exact| max %.2e median %.2e (iterations up to %d)' % (T, name, d.max(), np.median(d), it.max()))
+        assert d.max() < BAR, (name, d.max())
+
+
+def test_committed_corpus_vs_exact_minimiser(ctx):
+    """tests/golden/qp_corpus.npz: the hardest and the formerly least accurate problems of a harvest (up to 22 iterations, up to 1e-3 from
+    the optimum before the polish), kept as a fixture so that the CPU suite sees them too (tests/test_oracle_qp.py)"""
+    g = H.gold('qp_corpus.npz')
+    res, it = _distances(ctx, 20, g['x0'], g['xref'], g['xbar'], g['re'], g['uw'])
+    for name, d in res.items():
+        print('%s: max %.2e (before the polish: %.2e)' % (name, d.max(), g['dist_before_polish'].max()))
+        assert d.max() < BAR, (name, d.max())

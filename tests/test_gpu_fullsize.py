@@ -20,8 +20,9 @@ def ctx():
 def _replay_all_on_oracle(sim, before, after, threads=16, tol=2e-7, dead=None):
     """EVERY agent of the step before -> after replayed on the oracle (orc_agent_steps_mt: the whole per-agent step in C, pthreads
     over agents) from the device state `before`: integer decisions and solver status must be identical for every agent, solutions
-    within tol (agents whose iteration count differs from the oracle's: within 1e-5).  Returns (worst |solution difference|, agents
-    whose iteration count differs, failed solves)."""
+    within tol -- ONE tolerance for every agent, whatever its iteration count: since the active-set polish of round 3 both sides end
+    on the same KKT point even where an exit test on the edge of its tolerance sends them there by different routes.  Returns (worst
+    |solution difference|, agents whose iteration count differs, failed solves)."""
     from oracle import oracle_py as orc
     import dataclasses
     po = orc.MpcParams(**{f.name: getattr(sim.params, f.name) for f in dataclasses.fields(orc.MpcParams)})
@@ -45,12 +46,8 @@ def _replay_all_on_oracle(sim, before, after, threads=16, tol=2e-7, dead=None):
     ok = (after['status'] == 0) & live
     diff = np.maximum(np.abs(r['u'] - after['u']).max((1, 2)), np.abs(r['x'] - after['x']).max((1, 2)))
     same_count = o[:, 5] == after['iters']
-    worst = float(diff[ok & same_count].max()) if (ok & same_count).any() else 0.0
-    assert worst < tol, worst
-    # an exit test decided on the edge of its tolerance (residual within rounding of tol * |g|) ends one side an iteration earlier:
-    # both iterates are accepted solutions, one step of the iteration apart (callers bound how many agents may do that)
-    edge = float(diff[ok & ~same_count].max()) if (ok & ~same_count).any() else 0.0
-    assert edge < 1e-5, edge
+    worst = float(diff[ok].max()) if ok.any() else 0.0
+    assert worst < tol, (worst, int(diff[ok].argmax()))
     return worst, int((~same_count).sum()), int((~ok).sum())
 
 

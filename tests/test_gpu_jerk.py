@@ -65,7 +65,7 @@ def test_jerk_qp_vs_oracle_and_exact_solution(ctx, T):
     print('T=%d jerk: |gpu - oracle| %.2e, |gpu - exact| max %.2e median %.2e, %d of %d iteration counts differ' %
           (T, worst, dist.max(), np.median(dist), it_diff, n))
     assert worst < QP_TOL and it_diff <= max(1, n // 20)
-    assert dist.max() < 1e-4 and np.median(dist) < 1e-7      # 1e-4: the stated tolerance against the reference's optimum
+    assert dist.max() < 5e-6 and np.median(dist) < 1e-7      # (1e-4 is the stated tolerance against the reference's optimum)
 
 
 def test_jerk_long_horizon_kernel(ctx):

@@ -103,7 +103,7 @@ def test_qp_vs_exact_active_set_solution(ctx, solver):
         dist.append(np.abs(z - ex['z']).max())
     dist = np.array(dist)
     print('%s: |z_gpu - z_exact| max %.2e median %.2e' % (solver, dist.max(), np.median(dist)))
-    assert dist.max() < 1e-4 and np.median(dist) < 1e-7      # 1e-4: the stated tolerance against the reference's optimum
+    assert dist.max() < 5e-6 and np.median(dist) < 1e-7      # (1e-4 is the stated tolerance against the reference's optimum; at scale: tests/test_gpu_accuracy.py)
 
 
 @pytest.mark.parametrize('solver', ['condensed', 'stage', 'auto'])
@@ -140,7 +140,7 @@ def test_qp_hard_instance_from_the_soak(ctx, solver):
         sol = orc.qp_solve(po, st[k], xref[k], xbar[k], re[k], uw[k])
         # the soak's instance stagnates (stationarity stalls near 4e-7 * |g|, exit by the reduced-accuracy rule): two implementations
         # of the same iteration part ways in the last digits there
-        assert sol.status == 0 and np.abs(sol.u - u[k]).max() < (1e-6 if k == 15 else QP_TOL), k
+        assert sol.status == 0 and np.abs(sol.u - u[k]).max() < QP_TOL, k
 
 
 @pytest.mark.parametrize('solver', ['condensed', 'stage'])
@@ -163,7 +163,7 @@ def test_qp_creeping_instance(ctx, solver):
     sol = orc.qp_solve(orc.MpcParams(T=T), g['x0'][0], g['xref'][0], g['xbar'][0], g['re'][0], g['uw'][0])
     assert sol.status == 0 and out['status'].item() == 0
     assert abs(out['iters'].item() - sol.iters) <= 2
-    assert np.abs(out['u'].cpu().numpy()[0] - sol.u).max() < 1e-6          # stagnating instance: see test_qp_hard_instance_from_the_soak
+    assert np.abs(out['u'].cpu().numpy()[0] - sol.u).max() < QP_TOL
 
 
 def test_qp_warm_start_and_infeasible(ctx):

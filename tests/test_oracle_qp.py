@@ -21,7 +21,7 @@ def test_kkt_certificate_of_literal_problem(T):
         assert sol.status == 0
         c = QL.kkt_certificate(p, st, xref, xbar, re, sol.x, sol.u)
         assert c['eq'] < 1e-9, c            # dynamics + initial state rows of mpc.py:175,186
-        assert c['ineq'] < 1e-9, c          # bounds of mpc.py:184-191
+        assert c['ineq'] < 1e-8, c          # bounds of mpc.py:184-191 (a polished point holds its active rows to |lam - lam_ipm| / rho, rho = 1e8; ECOS's feastol is 1e-8)
         assert c['stat'] < 1e-6 * c['grad_scale'], c     # stationarity with multipliers >= 0 ...
         assert c['comp'] < 1e-6 * c['grad_scale'], c     # ... that vanish on rows with slack
 
@@ -30,9 +30,10 @@ def test_kkt_certificate_of_literal_problem(T):
 def test_exact_active_set_solution_pins_the_oracle(T):
     """The tightest pin available while ECOS cannot run: for EVERY golden problem the exact minimiser of the literal problem
     (active-set KKT solve, numpy.linalg.solve, tests/qp_literal.exact_solution) and the oracle's interior-point answer.
-    The exact point is a KKT point to rounding; the oracle stops at relative residual 1e-10 * |g| with Hessian eigenvalues down
-    to 2R = 0.02, i.e. up to a few 1e-5 from the optimum in the worst-conditioned problems (observed: worst 5.2e-5, median 5e-10) --
-    inside the 1e-4 stated as tolerance against the reference's optimum, and what any residual-based solver (ECOS included) delivers."""
+    The exact point is a KKT point to rounding.  Until round 2 the oracle returned its interior-point iterate (relative residual
+    1e-10 * |g|, Hessian eigenvalues down to 2R = 0.02: up to 5e-5 from the optimum on this set, and up to 1e-3 on harvested closed-loop
+    problems at the reduced-accuracy exit); since round 3 every constrained solve ends with the active-set polish (oracle.c: polish(),
+    same rule in both HIP solvers) on a verified KKT point: observed worst 1e-7.  Bar 5e-6 (north star: 1e-4 against the reference's optimum)."""
     g = H.gold('mpc_pre.npz')
     p = orc.MpcParams(T=T)
     dist = []
@@ -49,7 +50,7 @@ def test_exact_active_set_solution_pins_the_oracle(T):
         assert abs(fo - ex['obj']) <= 1e-8 * max(1.0, abs(ex['obj'])), (k, fo, ex['obj'])
         dist.append(np.abs(zo - ex['z']).max())
     dist = np.array(dist)
-    assert dist.max() < 1e-4, dist.max()                        # the stated tolerance against the reference's optimum
+    assert dist.max() < 5e-6, dist.max()                        # (the stated tolerance against the reference's optimum is 1e-4)
     assert np.median(dist) < 1e-7, np.median(dist)
 
 
@@ -111,3 +112,25 @@ def test_trial_step_returns_the_unconstrained_minimiser():
             ex = QL.exact_solution(p, x0, xref, xbar, re, QL.pack(p, sol.x, sol.u))
             assert len(ex['active']) == 0 and np.abs(ex['z'] - QL.pack(p, sol.x, sol.u)).max() < 1e-10
     assert n0 >= 30, n0
+
+
+def test_hard_closed_loop_corpus_vs_exact_minimiser():
+    """tests/golden/qp_corpus.npz: ~400 QPs harvested from the benchmark's closed loop on the GPU box (scripts/harvest_qp.py) -- the
+    hardest (up to 22 iterations) and the ones on which the interior-point iterate alone was least accurate (up to 1e-3 from the optimum at
+    the reduced-accuracy exit: `dist_before_polish`), plus a random sample.  With the active-set polish the oracle lands within 1e-6 of
+    the exact minimiser of the literal problem on every one of them."""
+    g = H.gold('qp_corpus.npz')
+    p = orc.MpcParams(T=20)
+    dist, its = [], []
+    for k in range(len(g['iters'])):
+        sol = orc.qp_solve(p, g['x0'][k], g['xref'][k], g['xbar'][k], g['re'][k], g['uw'][k])
+        assert sol.status == 0
+        z = QL.pack(p, sol.x, sol.u)
+        ex = QL.exact_solution(p, g['x0'][k], g['xref'][k], g['xbar'][k], g['re'][k], z)
+        assert ex['eq'] < 1e-9 and (ex['lam'] >= -1e-7).all() and ex['slack'].min() > -1e-9, k
+        dist.append(np.abs(z - ex['z']).max()); its.append(sol.iters)
+    dist = np.array(dist)
+    print('oracle vs exact on %d harvested problems: max %.2e p99 %.2e median %.2e; iterations up to %d (before the polish: up to %d, distance up to %.1e)'
+          % (len(dist), dist.max(), np.quantile(dist, .99), np.median(dist), max(its), g['iters'].max(), g['dist_before_polish'].max()))
+    assert g['dist_before_polish'].max() > 5e-4           # the fixture really holds the problems the plain iteration got wrong
+    assert dist.max() < 5e-6, (dist.max(), int(dist.argmax()))
