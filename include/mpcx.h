@@ -91,6 +91,16 @@ int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double *state /*B
                                const int32_t *path_off /*B*/,
                                const int32_t *path_len /*B*/, double dl, int32_t *target_ind /*B in-out*/,
                                double *xref /*B,4,T+1*/, uint8_t *reaches_end /*B,T+1*/, double *xbar /*B,4,T+1*/);
+/* the same for the second and later of MAX_ITER linearisation passes (lib/mpc.py:226-237 `_iterative_linear_mpc_control`): `ov`, the
+ * speeds of the previous pass's solution (row 2 of its x, T+1 values per instance, instance b at ov + b * ov_stride), spaces the
+ * reference window (mpc.py:95-98 with ov given) and u_warm = the previous pass's inputs makes the rollout (mpc.py:231).  ov = NULL is
+ * mpcx_mpc_prepare_batch. */
+int32_t mpcx_mpc_prepare_batch_ov(mpcx_ctx *ctx, int32_t B, const double *state, const double *u_warm,
+                                  const double *path_xyyaw, const double *path_v, const int32_t *path_off, const int32_t *path_len,
+                                  double dl, int32_t *target_ind, const double *ov /*or NULL*/, int64_t ov_stride,
+                                  double *xref, uint8_t *reaches_end, double *xbar);
+/* lib/mpc.py:226 `for _ in range(MAX_ITER)` inside mpcx_closed_loop_run: passes >= 1 (default 1 = the stock mpc_config.json) */
+int32_t mpcx_set_linearisation_passes(mpcx_ctx *ctx, int32_t passes);
 
 /* ---- lib/motion_primitive_search.py:87-121 `neighbor_function` (+ obstacles.py:157-176 `check_collision`,
  * linalg.py:4-54, maths.py:4-10).  Model tables are copied to the device once by mpcx_search_model_create

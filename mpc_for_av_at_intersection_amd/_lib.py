@@ -49,7 +49,8 @@ EXPORTS = ['mpcx_create', 'mpcx_destroy', 'mpcx_last_error', 'mpcx_version', 'mp
            'mpcx_expand_batch', 'mpcx_interaction_batch', 'mpcx_moving_collision_batch', 'mpcx_plant_step_batch',
            'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch', 'mpcx_selftest_wave_ops', 'mpcx_selftest_mfma',
            'mpcx_closed_loop_run', 'mpcx_profile_qp', 'mpcx_profile_qp_read', 'mpcx_set_instance_tuning', 'mpcx_set_qp_solver', 'mpcx_qp_set_order_hint', 'mpcx_expand_multi_batch',
-           'mpcx_comm_unique_id', 'mpcx_comm_init', 'mpcx_comm_destroy', 'mpcx_allgather_states', 'mpcx_closed_loop_stats']
+           'mpcx_comm_unique_id', 'mpcx_comm_init', 'mpcx_comm_destroy', 'mpcx_allgather_states', 'mpcx_closed_loop_stats',
+           'mpcx_mpc_prepare_batch_ov', 'mpcx_set_linearisation_passes']
 
 
 def load():
@@ -72,6 +73,9 @@ def load():
     lib.mpcx_qp_solve_batch.restype = i32; lib.mpcx_qp_solve_batch.argtypes = [vp, i32] + [vp] * 10
     lib.mpcx_mpc_prepare_batch.restype = i32
     lib.mpcx_mpc_prepare_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp, vp, vp]
+    lib.mpcx_mpc_prepare_batch_ov.restype = i32
+    lib.mpcx_mpc_prepare_batch_ov.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp, C.c_int64, vp, vp, vp]
+    lib.mpcx_set_linearisation_passes.restype = i32; lib.mpcx_set_linearisation_passes.argtypes = [vp, i32]
     lib.mpcx_search_model_create.restype = vp
     lib.mpcx_search_model_create.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.mpcx_search_model_destroy.restype = None; lib.mpcx_search_model_destroy.argtypes = [vp]

@@ -91,6 +91,7 @@ class IntersectionBatch:
                         status=torch.zeros(P, dtype=torch.int32, device=dev), iters=torch.zeros(P, dtype=torch.int32, device=dev),
                         kkt=torch.zeros((P, 4), dtype=f, device=dev))
         self.steps_done = 0
+        self.lin_passes = 1          # lib/mpc.py MAX_ITER: (window, rollout, QP) passes per step; the stock mpc_config.json has 1
         self.path_v = None
         self.tuning = None
         if tuning is not None:
@@ -125,6 +126,8 @@ class IntersectionBatch:
         changed it since this batch was built"""
         if self.ctx.params != self.params:
             self.ctx.set_mpc_params(self.params)
+        if getattr(self.ctx, 'lin_passes', 1) != self.lin_passes:
+            self.ctx.set_linearisation_passes(self.lin_passes)
         self.ctx.set_instance_tuning(self.tuning)
 
     def run(self, n_steps: int, graph: bool = False):
@@ -173,8 +176,10 @@ class IntersectionBatch:
                       self.inter['cut_len'], self.obs6, self.obs_off, self.obs_cnt, self.obs_skip,
                       self.traj_idx, out=self.inter)
         # the previous solution (zeros where the last solve failed or on the first step) is the warm start
-        c.prepare(self.state, self.sol['u'], self.path, self.path_off, self.inter['cut_len'], self.dl, self.target_ind, out=self.pre)
-        c.qp_solve(self.state, self.pre['xref'], self.pre['xbar'], self.pre['reaches_end'], self.sol['u'], out=self.sol)
+        for it in range(self.lin_passes):       # lib/mpc.py:226-237: from the second pass on the previous pass's speeds space the window
+            c.prepare(self.state, self.sol['u'], self.path, self.path_off, self.inter['cut_len'], self.dl, self.target_ind, out=self.pre,
+                      x_prev=self.sol['x'] if it else None)
+            c.qp_solve(self.state, self.pre['xref'], self.pre['xbar'], self.pre['reaches_end'], self.sol['u'], out=self.sol)
         c.plant_step(self.state, self.sol['u'], self.sol['status'], self.applied)
         self.steps_done += 1
 

@@ -117,6 +117,13 @@ int32_t mpcx_set_qp_solver(mpcx_ctx *ctx, int32_t which) {
     return MPCX_OK;
 }
 
+int32_t mpcx_set_linearisation_passes(mpcx_ctx *ctx, int32_t passes) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (passes < 1 || passes > 16) return mpcx_fail(ctx, MPCX_E_INVALID, "set_linearisation_passes: 1..16 (lib/mpc.py MAX_ITER)");
+    ctx->lin_passes = passes;
+    return MPCX_OK;
+}
+
 int32_t mpcx_profile_qp(mpcx_ctx *ctx, int32_t enable) {
     if (!ctx) return MPCX_E_INVALID;
     ctx->prof_qp = enable != 0;

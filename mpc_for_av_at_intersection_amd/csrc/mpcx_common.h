@@ -27,6 +27,7 @@ struct mpcx_ctx {
     void *multi;                // scratch of mpcx_expand_multi_batch (segment descriptors + block tables)
     size_t multi_cap;
     int qp_solver;              // 0 = automatic, 1 = condensed (one wavefront per QP), 2 = stage-structured (mpcx_set_qp_solver)
+    int lin_passes = 1;         // linearisation passes per step of mpcx_closed_loop_run (lib/mpc.py MAX_ITER; mpcx_set_linearisation_passes)
     bool prof_qp;               // bracket qp_kernel launches with events (mpcx_profile_qp)
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs recorded so far
     std::vector<hipEvent_t> prof_free; // recycled events

@@ -49,16 +49,22 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
                                 c->cut_len /* previous step's cut; read before it is rewritten */, pool_rows, c->obs6,
                                 c->obs_off, c->obs_cnt, c->obs_skip, c->traj_idx, c->hit_idx, c->hit_xy, c->cut_len);
     if (rc != MPCX_OK) return rc;
-    rc = mpcx_mpc_prepare_batch(ctx, P, c->state, c->u_sol, c->path_xyyaw, c->path_v, c->path_off, c->cut_len, c->dl,
-                                c->target_ind, c->xref, c->reaches_end, c->xbar);
-    if (rc != MPCX_OK) return rc;
-    // hard problems first: the previous step's iteration counts (zero-initialised by the caller) order the work queue
-    const int32_t *hint_before = ctx->order_hint, *now_before = ctx->order_now, *prev_before = ctx->order_prev;
-    ctx->order_hint = c->iters; ctx->order_now = c->cut_len; ctx->order_prev = ctx->prev_cut;
-    rc = mpcx_qp_solve_batch(ctx, P, c->state, c->xref, c->xbar, c->reaches_end, c->u_sol, c->x_sol, c->u_sol,
-                             c->status, c->iters, c->kkt);
-    ctx->order_hint = hint_before; ctx->order_now = now_before; ctx->order_prev = prev_before;
-    if (rc != MPCX_OK) return rc;
+    // lib/mpc.py:226-237: MAX_ITER passes of (reference window, rollout, QP); from the second pass on the window is spaced by the
+    // previous pass's speeds (row 2 of its x) and the rollout uses its inputs.  (Where a pass fails the reference crashes in the next
+    // one -- zip over None; here the next pass starts from the untouched warm start, as after a failed step.)
+    const int Wd = ctx->mpc.T + 1;
+    for (int pass = 0; pass < ctx->lin_passes; pass++) {
+        rc = mpcx_mpc_prepare_batch_ov(ctx, P, c->state, c->u_sol, c->path_xyyaw, c->path_v, c->path_off, c->cut_len, c->dl,
+                                       c->target_ind, pass ? c->x_sol + 2 * Wd : nullptr, 4 * (int64_t)Wd, c->xref, c->reaches_end, c->xbar);
+        if (rc != MPCX_OK) return rc;
+        // hard problems first: the previous step's iteration counts (zero-initialised by the caller) order the work queue
+        const int32_t *hint_before = ctx->order_hint, *now_before = ctx->order_now, *prev_before = ctx->order_prev;
+        ctx->order_hint = c->iters; ctx->order_now = c->cut_len; ctx->order_prev = ctx->prev_cut;
+        rc = mpcx_qp_solve_batch(ctx, P, c->state, c->xref, c->xbar, c->reaches_end, c->u_sol, c->x_sol, c->u_sol,
+                                 c->status, c->iters, c->kkt);
+        ctx->order_hint = hint_before; ctx->order_now = now_before; ctx->order_prev = prev_before;
+        if (rc != MPCX_OK) return rc;
+    }
     ctx->stats_iters = c->iters;
     rc = mpcx_plant_step_batch(ctx, P, c->state, c->u_sol, c->status, c->applied);
     ctx->stats_iters = nullptr;
@@ -125,7 +131,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     if (ctx->prof_qp)       // the event pairs of mpcx_profile_qp cannot be recorded inside a replayed graph: say so instead of reporting 0 launches
         return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: mpcx_profile_qp is on; the QP launches of a replayed graph are not bracketed by events -- run without graph or switch the hook off");
     unsigned char key[sizeof ctx->loop_key];
-    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 7 * sizeof(void *) <= sizeof key,
+    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 8 * sizeof(void *) <= sizeof key,
                   "loop_key too small");
     memset(key, 0, sizeof key);
     size_t o = 0;
@@ -137,6 +143,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     memcpy(key + o, &ctx->order, sizeof ctx->order); o += sizeof ctx->order;
     memcpy(key + o, &ctx->prev_cut, sizeof ctx->prev_cut); o += sizeof ctx->prev_cut;
     memcpy(key + o, &ctx->qp_solver, sizeof ctx->qp_solver); o += sizeof ctx->qp_solver;      // the captured launch is the solver chosen at capture time
+    memcpy(key + o, &ctx->lin_passes, sizeof ctx->lin_passes); o += sizeof ctx->lin_passes;
     memcpy(key + o, &ctx->stats, sizeof ctx->stats);
     if (!ctx->loop_exec || memcmp(key, ctx->loop_key, sizeof key) != 0) {
         if (ctx->loop_exec) {

@@ -20,6 +20,8 @@ struct RefArgs {
     int32_t *target_ind;
     double *xref;
     uint8_t *re;
+    const double *ov;       // speeds of the previous linearisation pass (mpc.py:226-237, MAX_ITER > 1): row b at ov + b * ov_stride, or nullptr
+    long ov_stride;
 };
 
 __device__ __forceinline__ void ref_window_block(const RefArgs &a, int b) {
@@ -39,11 +41,13 @@ __device__ __forceinline__ void ref_window_block(const RefArgs &a, int b) {
         return;
     }
     // mpc.py:95-100: ov = max(v, 10/3.6); travel = cumsum(|ov|*dt); idx = min(rint(travel/dl) + s, n-1)
+    // from the second of MAX_ITER linearisation passes on, ov = the previous pass's speeds (mpc.py:226-237)
     const double ov = v > 10.0 / 3.6 ? v : 10.0 / 3.6;
     const double step = __dmul_rn(fabs(ov), a.p.dt);
+    const double *ovp = a.ov ? a.ov + (size_t)b * a.ov_stride : nullptr;
     if (lane <= T) {
-        double travel = step;                       // np.cumsum: sequential adds
-        for (int k = 1; k <= lane; k++) travel = __dadd_rn(travel, step);
+        double travel = ovp ? __dmul_rn(fabs(ovp[0]), a.p.dt) : step;                       // np.cumsum: sequential adds
+        for (int k = 1; k <= lane; k++) travel = __dadd_rn(travel, ovp ? __dmul_rn(fabs(ovp[k]), a.p.dt) : step);
         long long idx = (long long)rint(__ddiv_rn(travel, a.dl)) + s;
         if (idx > n - 1) idx = n - 1;
         xr[0 * W + lane] = path[3 * idx];
@@ -162,13 +166,22 @@ __global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
 extern "C" int32_t mpcx_mpc_prepare_batch(mpcx_ctx *ctx, int32_t B, const double *state, const double *u_warm,
                                           const double *path_xyyaw, const double *path_v, const int32_t *path_off,
                                           const int32_t *path_len, double dl, int32_t *target_ind, double *xref, uint8_t *reaches_end, double *xbar) {
+    return mpcx_mpc_prepare_batch_ov(ctx, B, state, u_warm, path_xyyaw, path_v, path_off, path_len, dl, target_ind, nullptr, 0, xref, reaches_end, xbar);
+}
+
+extern "C" int32_t mpcx_mpc_prepare_batch_ov(mpcx_ctx *ctx, int32_t B, const double *state, const double *u_warm,
+                                             const double *path_xyyaw, const double *path_v, const int32_t *path_off,
+                                             const int32_t *path_len, double dl, int32_t *target_ind, const double *ov, int64_t ov_stride,
+                                             double *xref, uint8_t *reaches_end, double *xbar) {
     if (!ctx) return MPCX_E_INVALID;
     if (!ctx->have_mpc) return mpcx_fail(ctx, MPCX_E_INVALID, "mpcx_set_mpc_params has not been called");
     if (B == 0) return MPCX_OK;       // empty batch: nothing to do (zero-size tensors have null data pointers)
     if (B < 0 || !state || !path_xyyaw || !path_off || !path_len || !target_ind || !xref || !reaches_end || !xbar || !(dl > 0))
         return mpcx_fail(ctx, MPCX_E_INVALID, "mpc_prepare_batch: null pointer, negative batch or dl <= 0");
     if (B == 0) return MPCX_OK;
-    mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end};
+    if (ov && ov_stride < (int64_t)ctx->mpc.T + 1)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "mpc_prepare_batch_ov: ov_stride %lld is smaller than T + 1", (long long)ov_stride);
+    mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end, ov, (long)ov_stride};
     mpcx::RollArgs ro{ctx->mpc, B, state, u_warm, xbar};
     hipLaunchKernelGGL(mpcx::prepare_kernel, dim3((B + mpcx::PREP_WAVES - 1) / mpcx::PREP_WAVES + (B + 64 * mpcx::PREP_WAVES - 1) / (64 * mpcx::PREP_WAVES)),
                        dim3(64 * mpcx::PREP_WAVES), 0, ctx->stream, ra, ro);

@@ -139,10 +139,6 @@ class MPC:
 
     # ------------------------------------------------------------------ one control step (mpc.py:280-299)
     def step(self, state: State) -> Tuple[float, float]:
-        if self._max_iter() != 1:
-            # the reference re-linearises MAX_ITER times and spaces the reference window by the previous pass's speeds (mpc.py:226-237);
-            # its config has MAX_ITER = 1 and the kernels implement that one pass (window spacing from the current speed)
-            raise NotImplementedError('MAX_ITER = %r: only the single linearisation pass of the stock configuration is implemented' % (self._max_iter(),))
         ctx = self._ctx
         p = self._make_params()
         if ctx.params != p:
@@ -153,12 +149,20 @@ class MPC:
         if self.oa is not None and self.odelta is not None:
             warm = ctx.f64(np.stack([np.asarray(self.oa, float), np.asarray(self.odelta, float)])[None])
         tind = ctx.i32([self.target_ind])
-        pre = ctx.prepare(x0, warm, self._dev_path, ctx.i32([0]), ctx.i32([len(self.cx)]), float(self.dl), tind)
-        sol = ctx.qp_solve(x0, pre['xref'], pre['xbar'], pre['reaches_end'], warm)
-        ctx.synchronize()
-        ti = int(tind.cpu()[0])
-        if ti < 0:
-            raise Exception("something wrong")             # trajectories.py:120
+        # _iterative_linear_mpc_control (mpc.py:211-237): MAX_ITER passes of (reference window, rollout, QP); from the second pass on
+        # the window is spaced by the previous pass's speeds `ov` and the rollout uses its inputs.  Stock configuration: one pass.
+        sol = None
+        for it in range(max(1, self._max_iter())):
+            if it > 0 and int(sol['status'].cpu()[0]) != 0:
+                # the reference's failed solve returns oa = None and its next pass dies in _predict_motion's zip(oa, od, ...)
+                raise TypeError("zip argument #1 must support iteration")
+            pre = ctx.prepare(x0, warm if it == 0 else sol['u'], self._dev_path, ctx.i32([0]), ctx.i32([len(self.cx)]), float(self.dl), tind,
+                              x_prev=None if it == 0 else sol['x'])
+            sol = ctx.qp_solve(x0, pre['xref'], pre['xbar'], pre['reaches_end'], warm if it == 0 else sol['u'].clone())
+            ctx.synchronize()
+            ti = int(tind.cpu()[0])
+            if ti < 0:
+                raise Exception("something wrong")             # trajectories.py:120
         self.target_ind = ti
         self.xref = pre['xref'].cpu().numpy()[0]
         self.status = int(sol['status'].cpu()[0]); self.iters = int(sol['iters'].cpu()[0])

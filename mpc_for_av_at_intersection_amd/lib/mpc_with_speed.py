@@ -72,12 +72,18 @@ class MPC:
             warm = ctx.f64(np.stack([np.asarray(self.oa, float), np.asarray(self.odelta, float)])[None])
         tind = ctx.i32([self.target_ind])
         path = ctx.f64(np.column_stack([self.cx, self.cy, self.cyaw]))
-        pre = ctx.prepare(x0, warm, path, ctx.i32([0]), ctx.i32([len(self.cx)]), float(self.dl), tind, path_v=ctx.f64(self.cv))
-        sol = ctx.qp_solve(x0, pre['xref'], pre['xbar'], pre['reaches_end'], warm)
-        ctx.synchronize()
-        ti = int(tind.cpu()[0])
-        if ti < 0:
-            raise Exception("something wrong")
+        pv = ctx.f64(self.cv)
+        sol = None
+        for it in range(max(1, int(globals()['MAX_ITER']))):      # mpc_with_speed.py: the same MAX_ITER loop as lib/mpc.py:226-237
+            if it > 0 and int(sol['status'].cpu()[0]) != 0:
+                raise TypeError("zip argument #1 must support iteration")      # what the reference's next pass does with oa = None
+            pre = ctx.prepare(x0, warm if it == 0 else sol['u'], path, ctx.i32([0]), ctx.i32([len(self.cx)]), float(self.dl), tind, path_v=pv,
+                              x_prev=None if it == 0 else sol['x'])
+            sol = ctx.qp_solve(x0, pre['xref'], pre['xbar'], pre['reaches_end'], warm if it == 0 else sol['u'].clone())
+            ctx.synchronize()
+            ti = int(tind.cpu()[0])
+            if ti < 0:
+                raise Exception("something wrong")
         self.target_ind = ti
         self.xref = pre['xref'].cpu().numpy()[0]
         self.status = int(sol['status'].cpu()[0])

@@ -82,7 +82,15 @@ class InteractionParams:
         p = _lib.InteractionParamsC()
         p.pred_steps, p.frame_window, p.cutoff_margin, p.max_path_len = int(self.pred_steps), int(self.frame_window), int(self.cutoff_margin), int(self.max_path_len)
         p.dt, p.L, p.radius = float(self.dt), float(self.L), float(self.radius)
-        p.circle_centers[:] = list(map(float, self.circle_centers))
+        cc = list(map(float, np.asarray(self.circle_centers, dtype=np.float64).ravel()))
+        if len(cc) == 2:
+            # car_dimensions.py:51-75 with skip_back_circle_collision_checking=True: ONE disc.  The kernels test two; the same disc twice
+            # gives the reference's one-disc answers (every test is a min / first-hit over the discs, and the frame index is taken
+            # modulo the path length, collision_avoidance.py:92-98)
+            cc = cc + cc
+        if len(cc) != 4:
+            raise MpcxError('car_dimensions.circle_centers must hold one or two discs (x, y offsets), got %d numbers' % len(cc))
+        p.circle_centers[:] = cc
         p.max_accel, p.max_speed = float(self.max_accel), float(self.max_speed)
         return p
 
@@ -190,8 +198,10 @@ class Context:
         return out
 
     @_ordered
-    def prepare(self, state, u_warm, path, path_off, path_len, dl, target_ind, out=None, path_v=None):
-        """mpcx_mpc_prepare_batch. target_ind is updated in place. Returns dict(xref, reaches_end, xbar)."""
+    def prepare(self, state, u_warm, path, path_off, path_len, dl, target_ind, out=None, path_v=None, x_prev=None):
+        """mpcx_mpc_prepare_batch. target_ind is updated in place. Returns dict(xref, reaches_end, xbar).
+        x_prev (B, 4, T+1): the previous linearisation pass's states -- its speeds space the reference window (lib/mpc.py:226-237,
+        MAX_ITER > 1; mpcx_mpc_prepare_batch_ov)."""
         T = self.params.T
         B = state.shape[0]
         f = torch.float64
@@ -204,9 +214,13 @@ class Context:
             out = dict(xref=torch.empty((B, 4, T + 1), dtype=f, device=self.device),
                        reaches_end=torch.empty((B, T + 1), dtype=torch.uint8, device=self.device),
                        xbar=torch.empty((B, 4, T + 1), dtype=f, device=self.device))
-        self._chk(self.lib.mpcx_mpc_prepare_batch(self._ctx, B, _ptr(state), _ptr(u_warm), _ptr(path), _ptr(path_v), _ptr(path_off),
-                                                  _ptr(path_len), C.c_double(float(dl)), _ptr(target_ind),
-                                                  _ptr(out['xref']), _ptr(out['reaches_end']), _ptr(out['xbar'])))
+        ov, stride = None, 0
+        if x_prev is not None:
+            self._want(x_prev, f, (B, 4, T + 1), 'x_prev')
+            ov, stride = x_prev.data_ptr() + 2 * (T + 1) * 8, 4 * (T + 1)
+        self._chk(self.lib.mpcx_mpc_prepare_batch_ov(self._ctx, B, _ptr(state), _ptr(u_warm), _ptr(path), _ptr(path_v), _ptr(path_off),
+                                                     _ptr(path_len), C.c_double(float(dl)), _ptr(target_ind), ov, stride,
+                                                     _ptr(out['xref']), _ptr(out['reaches_end']), _ptr(out['xbar'])))
         return out
 
     @_ordered
@@ -352,6 +366,11 @@ class Context:
     def set_qp_solver(self, which: str):
         """'auto', 'condensed' (one wavefront per QP) or 'stage' (stage-structured solver, eight lanes per QP)"""
         self._chk(self.lib.mpcx_set_qp_solver(self._ctx, {'auto': 0, 'condensed': 1, 'stage': 2}[which]))
+
+    def set_linearisation_passes(self, passes: int):
+        """lib/mpc.py MAX_ITER inside mpcx_closed_loop_run: (window, rollout, QP) passes per step (stock configuration: 1)"""
+        self._chk(self.lib.mpcx_set_linearisation_passes(self._ctx, int(passes)))
+        self.lin_passes = int(passes)
 
     def profile_qp(self, enable: bool):
         """bracket every qp_kernel launch with HIP events on the context's stream (mpcx_profile_qp)"""

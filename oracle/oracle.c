@@ -77,12 +77,21 @@ int32_t orc_nearest_index_in_direction(double x, double y, const double *cx, con
 int32_t orc_calc_ref_trajectory(const orc_mpc_params *p, const double *st, const double *cx, const double *cy,
                                 const double *cyaw, const double *cv /* NULL: lib/mpc.py; else mpc_with_speed.py:103-104 */,
                                 int32_t n, double dl, int32_t start_idx, double *xref, uint8_t *reaches_end) {
+    return orc_calc_ref_trajectory_ov(p, st, cx, cy, cyaw, cv, NULL, n, dl, start_idx, xref, reaches_end);
+}
+
+/* the same with the `ov` argument of mpc.py:86,95-98: the speeds of the previous linearisation pass (T+1 values; mpc.py:226-237 passes
+ * them from the second of MAX_ITER passes on) space the reference window instead of max(state.v, 10/3.6) */
+int32_t orc_calc_ref_trajectory_ov(const orc_mpc_params *p, const double *st, const double *cx, const double *cy,
+                                   const double *cyaw, const double *cv, const double *ov_prev /* T+1 or NULL */,
+                                   int32_t n, double dl, int32_t start_idx, double *xref, uint8_t *reaches_end) {
     int32_t T = p->T, W = T + 1;
     int32_t s = orc_nearest_index_in_direction(st[0], st[1], cx, cy, n, start_idx, 1);
     if (s < 0) return -1;
-    double ov = st[2] > 10.0 / 3.6 ? st[2] : 10.0 / 3.6;   /* max(state.v, 10/3.6); ov is None with MAX_ITER=1 */
-    double step = fabs(ov) * p->dt, travel = 0.0;
+    double ov = st[2] > 10.0 / 3.6 ? st[2] : 10.0 / 3.6;   /* max(state.v, 10/3.6) where ov is None (first pass) */
+    double travel = 0.0;
     for (int32_t k = 0; k < W; k++) {
+        double step = fabs(ov_prev ? ov_prev[k] : ov) * p->dt;
         travel = (k == 0) ? step : travel + step;          /* np.cumsum: sequential adds */
         long idx = (long)nearbyint(travel / dl);           /* np.rint: half-to-even under the default rounding mode */
         idx += s;

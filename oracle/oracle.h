@@ -49,6 +49,9 @@ void orc_xy_cost_mtx(double angle, double *M4);                                 
 void orc_smooth_yaw(double *yaw, int32_t n);                                     /* mpc.py:43-55 */
 int32_t orc_nearest_index_in_direction(double x, double y, const double *cx, const double *cy, int32_t n,
                                        int32_t start, int32_t forward);          /* trajectories.py:100-126; -1 = "something wrong" */
+int32_t orc_calc_ref_trajectory_ov(const orc_mpc_params *p, const double *state4, const double *cx, const double *cy,
+                                   const double *cyaw, const double *cv, const double *ov_prev /* T+1 or NULL */,
+                                   int32_t n, double dl, int32_t start_idx, double *xref, uint8_t *reaches_end);
 int32_t orc_calc_ref_trajectory(const orc_mpc_params *p, const double *state4 /*x,y,v,yaw*/,
                                 const double *cx, const double *cy, const double *cyaw, const double *cv /*or NULL*/, int32_t n, double dl,
                                 int32_t start_idx, double *xref /*4,(T+1)*/, uint8_t *reaches_end /*T+1*/); /* mpc.py:86-109; returns new start idx or -1 */

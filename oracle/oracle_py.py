@@ -39,6 +39,7 @@ def lib():
         _LIB.orc_nearest_index_in_direction.argtypes = [C.c_double, C.c_double, c_dp, c_dp, C.c_int32, C.c_int32, C.c_int32]
         _LIB.orc_nearest_index_in_direction.restype = C.c_int32
         _LIB.orc_calc_ref_trajectory.restype = C.c_int32
+        _LIB.orc_calc_ref_trajectory_ov.restype = C.c_int32
         _LIB.orc_qp_build.restype = C.c_int32
         _LIB.orc_qp_solve.restype = C.c_int32
         _LIB.orc_qp_build_jerk.restype = C.c_int32
@@ -141,16 +142,18 @@ def nearest_index_in_direction(x, y, cx, cy, start, forward=True):
     return lib().orc_nearest_index_in_direction(float(x), float(y), _d(cx), _d(cy), len(cx), int(start), int(forward))
 
 
-def calc_ref_trajectory(p: MpcParams, state4, cx, cy, cyaw, dl, start_idx, cv=None):
+def calc_ref_trajectory(p: MpcParams, state4, cx, cy, cyaw, dl, start_idx, cv=None, ov=None):
+    """mpc.py:86-109; ov = the previous linearisation pass's speeds (mpc.py:226-237, MAX_ITER > 1) or None"""
     cx = np.ascontiguousarray(cx, np.float64); cy = np.ascontiguousarray(cy, np.float64)
     cyaw = np.ascontiguousarray(cyaw, np.float64)
     st = np.ascontiguousarray(state4, np.float64)
     xref = np.zeros((4, p.T + 1)); re = np.zeros(p.T + 1, np.uint8)
     cp = p.c()
     cvv = None if cv is None else np.ascontiguousarray(cv, np.float64)
-    s = lib().orc_calc_ref_trajectory(C.byref(cp), _d(st), _d(cx), _d(cy), _d(cyaw), None if cvv is None else _d(cvv),
-                                      C.c_int32(len(cx)), C.c_double(dl),
-                                      C.c_int32(start_idx), _d(xref), _b(re))
+    ovv = None if ov is None else np.ascontiguousarray(ov, np.float64)
+    s = lib().orc_calc_ref_trajectory_ov(C.byref(cp), _d(st), _d(cx), _d(cy), _d(cyaw), None if cvv is None else _d(cvv),
+                                         None if ovv is None else _d(ovv), C.c_int32(len(cx)), C.c_double(dl),
+                                         C.c_int32(start_idx), _d(xref), _b(re))
     return xref, s, re
 
 

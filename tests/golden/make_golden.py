@@ -408,8 +408,11 @@ def stage_numpy():
     _savez('moving.npz', **mov)
 
 
-def stage_closedloop():
-    """G9: reference closed loop (mpc_intersection.py:95-159 sequence) with the oracle QP in place of ECOS."""
+def stage_closedloop(max_iter=1, horizons=(10, 13, 20), name='closedloop.npz', max_steps=400):
+    """G9: reference closed loop (mpc_intersection.py:95-159 sequence) with the oracle QP in place of ECOS.
+    max_iter > 1 (closedloop_iter2.npz): the reference's successive linearisation, mpc.py:226-237 -- MAX_ITER passes per step, the
+    reference window of every pass after the first spaced by the previous pass's speeds (`ov`), its rollout made with the previous
+    pass's inputs; one record per QP call (MAX_ITER per step)."""
     import numpy as np
     sys.path.insert(0, REPO)
     from oracle import oracle_py as orc
@@ -425,7 +428,8 @@ def stage_closedloop():
     import lib.mpc as rmpc
 
     out = {}
-    for T in (10, 13, 20):
+    rmpc.MAX_ITER = max_iter
+    for T in horizons:
         rmpc.T = T
         rmpc.Qf = np.diag([1.0, 1.0, 0.0, 0.5]) * T
         params = orc.MpcParams(T=T)
@@ -459,7 +463,7 @@ def stage_closedloop():
         margin = 4 * int(np.ceil(cd.radius / dl))
         tidx = 0
         tmp = None
-        for i in range(400):
+        for i in range(max_steps):
             if mpc.is_goal(state):
                 break
             if tmp is None or np.any(tmp[tidx, :] != tmp[-1, :]):
@@ -494,7 +498,46 @@ def stage_closedloop():
             out['T%d/%s' % (T, k)] = np.array(v)
         out['T%d/full' % T] = full  # yaw column already smoothed in place by MPC.__init__
         out['T%d/steps' % T] = np.array(i)
-    _savez('closedloop.npz', **out)
+    rmpc.MAX_ITER = 1
+    _savez(name, **out)
+
+
+def stage_onedisc():
+    """moving_onedisc.npz: the moving-car conflict chain of moving.npz (same inputs) for a car with ONE collision disc
+    (car_dimensions.py:51-75, skip_back_circle_collision_checking=True)."""
+    import numpy as np
+    from lib.car_dimensions import BicycleModelDimensions
+    from lib.trajectories import resample_curve
+    from lib.simulation import Simulation
+    from lib.collision_avoidance import check_collision_moving_cars, get_cutoff_curve_by_position_idx
+    from lib.moving_obstacles_prediction import MovingObstaclesPrediction
+    import lib.mpc as rmpc
+    mv = np.load(os.path.join(HERE, 'moving.npz'))
+    full = np.load(os.path.join(HERE, 'mpc_pre.npz'))['path_4_1']
+    one = BicycleModelDimensions(skip_back_circle_collision_checking=True)
+    assert one.circle_centers.shape == (1, 2)
+    margin = int(mv['moving/margin'])
+    hits, cuts = [], []
+    for k in range(len(mv['moving/in'])):
+        idx, v0, nobs = mv['moving/in'][k]
+        idx, nobs = int(idx), int(nobs)
+        traj = full[idx:]
+        if v0 < Simulation.MAX_SPEED:
+            rdl = np.zeros((traj.shape[0],)) + rmpc.MAX_ACCEL
+            rdl = 0.2 * np.minimum(np.cumsum(rdl) + v0, Simulation.MAX_SPEED)
+            tres = resample_curve(traj, dl=rdl)
+        else:
+            tres = resample_curve(traj, dl=0.2 * Simulation.MAX_SPEED)
+        assert len(tres) == mv['moving/nres'][k]
+        trajs = [np.vstack(MovingObstaclesPrediction(*s6, sample_time=0.2, car_dimensions=one).state_prediction(7.0)).T
+                 for s6 in mv['moving/obs'][k][:nobs]]
+        hit = check_collision_moving_cars(one, tres, traj, trajs, frame_window=20)
+        if hit is None:
+            hits.append([np.nan, np.nan, -1]); cuts.append(len(full))
+        else:
+            cut = max(idx + 1, get_cutoff_curve_by_position_idx(full, hit[0], hit[1]) - margin)
+            hits.append([hit[0], hit[1], hit[2]]); cuts.append(int(cut))
+    _savez('moving_onedisc.npz', hit=np.array(hits), cut=np.array(cuts, dtype=np.int32), circle_centers=one.circle_centers)
 
 
 def stage_traffic():
@@ -652,13 +695,17 @@ def stage_worlds():
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--stage', default='numpy', choices=['numpy', 'closedloop', 'traffic', 'worlds', 'all'])
+    ap.add_argument('--stage', default='numpy', choices=['numpy', 'closedloop', 'closedloop_iter2', 'onedisc', 'traffic', 'worlds', 'all'])
     a = ap.parse_args()
     _enter_reference()
     if a.stage in ('numpy', 'all'):
         stage_numpy()
     if a.stage in ('closedloop', 'all'):
         stage_closedloop()
+    if a.stage in ('closedloop_iter2', 'all'):
+        stage_closedloop(max_iter=2, horizons=(13,), name='closedloop_iter2.npz', max_steps=60)
+    if a.stage in ('onedisc', 'all'):
+        stage_onedisc()
     if a.stage in ('traffic', 'all'):
         stage_traffic()
     if a.stage in ('worlds', 'all'):

@@ -167,3 +167,20 @@ def test_context_on_a_stream_of_its_own():
         assert np.array_equal(u0, u1) and np.array_equal(i0, i1)
     finally:
         own.close(); ref.close()
+
+
+def test_linearisation_passes_batch_equals_staged(ctx):
+    """lib/mpc.py MAX_ITER > 1 in the batched closed loop: mpcx_closed_loop_run with mpcx_set_linearisation_passes(2) is bit-identical
+    to driving (interaction, [window with the previous pass's speeds, rollout, QP] x 2, plant) through the per-stage entry points, and
+    differs from the one-pass loop"""
+    from mpc_for_av_at_intersection_amd.batch import synthetic_batch
+    sims = [synthetic_batch(ctx, B=16, A=8, T=13, seed=5) for _ in range(3)]
+    sims[0].lin_passes = sims[1].lin_passes = 2
+    for _ in range(6):
+        sims[0].run(1)
+        sims[1].step_staged()
+        sims[2].run(1)
+    a, b, c = (s.snapshot() for s in sims)
+    for k in ('state', 'u', 'x', 'target_ind', 'cut_len', 'status', 'xref'):
+        assert np.array_equal(a[k], b[k]), k
+    assert (a['status'] == 0).all() and not np.array_equal(a['u'], c['u'])

@@ -99,7 +99,7 @@ def test_full_batch_closed_loop_properties(ctx):
     # 6. ALL 32768 agents replayed on the oracle from the same inputs: identical decisions and statuses, solutions <= 2e-7
     worst, it_diff, failed = _replay_all_on_oracle(sim, before, after)
     print('4096 x 8 agents vs oracle: worst %.2e, %d agents with a different iteration count, %d failed solves (same on both sides)' % (worst, it_diff, failed))
-    assert it_diff <= P // 1000
+    assert it_diff <= P // 1000, it_diff       # (observed since the polish: 0)
 
 
 def test_config3_1024_instances_8_agents(ctx):

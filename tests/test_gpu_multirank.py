@@ -46,7 +46,8 @@ def test_agent_sharded_two_ranks_bit_identical(tmp_path):
         for r, part in enumerate(parts):
             got = part[k].reshape((B, 4) + part[k].shape[1:])
             assert np.array_equal(got, full[:, 4 * r:4 * r + 4]), (k, r)
-    assert (ref['cut_len'] != ref['cut_len'].max()).any() or True
+    # the exchange mattered: within these steps some agent found a conflict with another agent and had its path cut
+    assert (ref['hit_idx'] >= 0).any(), 'no conflict in the reference run: the coupling was not exercised'
 
 
 def test_instance_sharded_two_ranks_bit_identical(tmp_path):

@@ -230,13 +230,19 @@ def test_expand_vs_golden(ctx, tag, version):
     assert np.array_equal(cost, np.broadcast_to(np.array(H.prim_meta(version)['total_length']), cost.shape))
 
 
-def test_interaction_vs_golden(ctx):
+@pytest.mark.parametrize('discs', [2, 1])
+def test_interaction_vs_golden(ctx, discs):
+    """discs = 1: a car with one collision disc (car_dimensions.py:51-75, skip_back_circle_collision_checking=True; golden
+    moving_onedisc.npz) -- the kernels are given the same disc twice"""
     from mpc_for_av_at_intersection_amd.runtime import InteractionParams
     mv = H.gold('moving.npz')
     full = H.gold('mpc_pre.npz')['path_4_1']
     car = H.car()
-    ip = InteractionParams(cutoff_margin=int(mv['moving/margin']), L=car['L'], radius=car['radius'],
-                           circle_centers=np.array(car['circle_centers']).ravel())
+    centers = np.array(car['circle_centers']) if discs == 2 else H.gold('moving_onedisc.npz')['circle_centers']
+    ip = InteractionParams(cutoff_margin=int(mv['moving/margin']), L=car['L'], radius=car['radius'], circle_centers=centers.ravel())
+    if discs == 1:
+        one = H.gold('moving_onedisc.npz')
+        mv = dict(mv); mv['moving/hit'] = one['hit']; mv['moving/cut'] = one['cut']
     n = len(mv['moving/in'])
     idx = mv['moving/in'][:, 0].astype(np.int32); v0 = mv['moving/in'][:, 1]; nobs = mv['moving/in'][:, 2].astype(np.int32)
     state = np.zeros((n, 4)); state[:, 0] = full[idx, 0]; state[:, 1] = full[idx, 1]; state[:, 2] = v0
