@@ -373,20 +373,31 @@ def main():
         try:
             n_all = 1 << 20
             nlo, nhi = sharding.shard_instances(n_all, rank, world)
-            model, nodes = prius_frontier(ctx, n_all, seed=0)
-            mine = nodes[nlo:nhi].contiguous()
-            out = ctx.expand(model, mine)
+            gold_logs = None
+            try:                                   # "plus all nodes of the golden expansion logs" (SURVEY 8(d) config 5): the Prius searches of the fixture
+                ar = np.load(os.path.join(ROOT, 'tests', 'golden', 'astar_runs.npz'))
+                gold_logs = np.concatenate([ar[k] for k in ar.files if k.startswith('mod_pri_') and k.endswith('/dbg_node')])
+            except Exception:
+                pass
             st = torch.cuda.current_stream(ctx.device)
             reps = 10
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            barrier()
-            e0.record(st)
-            for _ in range(reps):
-                ctx.expand(model, mine, out=out)
-            e1.record(st)
-            torch.cuda.synchronize()
-            ms = max_over_ranks(e0.elapsed_time(e1) / reps)
-            free_frac = sum_over_ranks(float((out['collide'] == 0).sum().item())) / (n_all * model.n_prim)
+
+            def time_frontier(free_space):
+                model, nodes = prius_frontier(ctx, n_all, seed=0, free_space=free_space, embed=gold_logs if free_space else None)
+                mine = nodes[nlo:nhi].contiguous()
+                out = ctx.expand(model, mine)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                barrier()
+                e0.record(st)
+                for _ in range(reps):
+                    ctx.expand(model, mine, out=out)
+                e1.record(st)
+                torch.cuda.synchronize()
+                ms_ = max_over_ranks(e0.elapsed_time(e1) / reps)
+                ff = sum_over_ranks(float((out['collide'] == 0).sum().item())) / (n_all * model.n_prim)
+                return model, ms_, ff
+            _, ms_uniform, ff_uniform = time_frontier(False)
+            model, ms, free_frac = time_frontier(True)
             bytes_node = 24 + model.n_prim * (24 + 8 + 1)
             fma_node = float(sum(model.n_pts_of) * 4 + sum(model.n_pts_of) * 3 * model.n_rows)
             nps = n_all / (ms * 1e-3)
@@ -397,11 +408,15 @@ def main():
                               'algorithmic_bytes_per_launch': bytes_node * n_all,
                               'hbm_frac': nps * bytes_node / 1e9 / (HBM_PEAK_GBS * world),
                               'fp64_fma_per_node_no_early_out': fma_node, 'fp64_equiv_frac_no_early_out': nps * fma_node * 2 / 1e12 / (FP64_PEAK_TFLOPS * world),
-                              'note': 'expand_kernel on a 2^20-node frontier (seed 0, uniform over the junction area), Prius primitives + PriusDimensions, '
-                                      'stock intersection obstacles; HIP events on the launch stream, mean of %d launches, nodes sharded evenly over the '
+                              'golden_log_nodes_embedded': 0 if gold_logs is None else int(len(gold_logs)),
+                              'uniform_frontier': {'ms': ms_uniform, 'nodes_per_s': n_all / (ms_uniform * 1e-3), 'free_fraction': ff_uniform,
+                                                   'hbm_frac': n_all / (ms_uniform * 1e-3) * bytes_node / 1e9 / (HBM_PEAK_GBS * world),
+                                                   'note': 'round 2\'s frontier (x, y uniform over the junction area whatever stands there): kept for comparison'},
+                              'note': 'expand_kernel on the frontier SURVEY 8(d) config 5 defines: 2^20 nodes (seed 0) sampled from FREE SPACE (poses at which the car '
+                                      'itself collides are rejected) with theta ~ U[-pi, pi), plus the nodes of the golden Prius expansion logs; Prius primitives + '
+                                      'PriusDimensions, stock intersection obstacles; HIP events on the launch stream, mean of %d launches, nodes sharded evenly over the '
                                       'GPUs (no exchange); bytes = 24 B read + P*(24+8+1) B written per node (SURVEY 8d); the FP64 figure is what the node rate would '
                                       'cost WITHOUT early-outs (every point x row test); it can exceed 1 because exact box culling skips most tests' % reps}
-            del out, mine, nodes
         except Exception as e:
             line['expand'] = {'error': repr(e)}
         # the two multi-rank extras create a second communicator and a second batch: a rank that fails inside one of them would

@@ -246,9 +246,15 @@ def synthetic_batch(ctx: Context, B: int, A: int = 8, T: int = 20, seed: int = 0
     return IntersectionBatch(ctx, params, ip, routes, dl, route_of_agent, start, agent_shard=agent_shard, exchange=exchange)
 
 
-def prius_frontier(ctx: Context, n: int = 1 << 20, seed: int = 0, extent: float = 40.0):
+def prius_frontier(ctx: Context, n: int = 1 << 20, seed: int = 0, extent: float = 40.0, free_space: bool = True, embed=None):
     """the search model of the Prius primitives + PriusDimensions on the stock intersection and a
-    frontier of n nodes (seeded: x, y uniform over the junction area, theta ~ U[-pi, pi)) as a device tensor."""
+    frontier of n nodes (seeded) as a device tensor.
+    free_space = True (the frontier section 8(d) defines): nodes "sampled from free space with theta ~ U[-pi, pi)" -- x, y uniform over
+    the junction area, REJECTING every pose at which the car itself collides (one of its two discs inside an obstacle inflated by
+    the disc radius: exactly the test check_collision makes on a pose, obstacles.py:157-176), so that no record leaves at a first hit
+    that the pose alone decides -- "plus all nodes of the golden expansion logs" (`embed`: (m, 3) array written over the first m
+    nodes; bench.py passes the Prius logs of tests/golden/astar_runs.npz).
+    free_space = False: round 2's frontier, x, y uniform over the junction area whatever stands there (60 % of its records collide)."""
     from .lib.car_dimensions import PriusDimensions
     from .lib.motion_primitive import load_motion_primitives
     from .lib.motion_primitive_search_modified import MotionPrimitiveSearch
@@ -256,5 +262,26 @@ def prius_frontier(ctx: Context, n: int = 1 << 20, seed: int = 0, extent: float 
     cd = PriusDimensions()
     search = MotionPrimitiveSearch(intersection(start_pos=2, turn_indicator=1), cd, load_motion_primitives('prius'), margin=cd.radius, ctx=ctx)
     rng = np.random.default_rng(seed)
-    nodes = np.column_stack([rng.uniform(-extent, extent, n), rng.uniform(-extent, extent, n), rng.uniform(-np.pi, np.pi, n)])
+
+    def draw(m):
+        return np.column_stack([rng.uniform(-extent, extent, m), rng.uniform(-extent, extent, m), rng.uniform(-np.pi, np.pi, m)])
+    if not free_space:
+        nodes = draw(n)
+    else:
+        hps = search._obstacles_hp                      # per obstacle: rows (a, b, c), inside <=> a x + b y + c <= 0 for every row
+        centers = np.asarray(cd.circle_centers, dtype=np.float64)
+        parts, have = [], 0
+        while have < n:
+            cand = draw(max(1 << 16, int(1.6 * (n - have))))
+            c, s = np.cos(cand[:, 2]), np.sin(cand[:, 2])
+            free = np.ones(len(cand), bool)
+            for ox, oy in centers:                      # disc centres of the car at the pose
+                px, py = cand[:, 0] + c * ox - s * oy, cand[:, 1] + s * ox + c * oy
+                for hp in hps:
+                    free &= ~((hp[:, 0][None, :] * px[:, None] + hp[:, 1][None, :] * py[:, None] + hp[:, 2][None, :]) <= 0.0).all(axis=1)
+            parts.append(cand[free]); have += int(free.sum())
+        nodes = np.concatenate(parts)[:n]
+    if embed is not None and len(embed):
+        e = np.asarray(embed, dtype=np.float64).reshape(-1, 3)[:n]
+        nodes[:len(e)] = e
     return search._model, ctx.f64(nodes)

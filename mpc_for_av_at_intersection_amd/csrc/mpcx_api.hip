@@ -66,6 +66,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
     if (ctx->order) (void)hipFree(ctx->order);
     if (ctx->multi) (void)hipFree(ctx->multi);
+    if (ctx->cs) (void)hipFree(ctx->cs);
     if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);

@@ -24,6 +24,8 @@ struct mpcx_ctx {
     size_t prev_cut_cap;
     int32_t *order;             // scratch: work-queue order built from the hint, and its two counters behind it
     size_t order_cap;
+    double *cs = nullptr;       // scratch of mpcx_expand_batch: (cos, sin) of the nodes' headings
+    size_t cs_cap = 0;
     void *multi;                // scratch of mpcx_expand_multi_batch (segment descriptors + block tables)
     size_t multi_cap;
     int qp_solver;              // 0 = automatic, 1 = condensed (one wavefront per QP), 2 = stage-structured (mpcx_set_qp_solver)

@@ -41,26 +41,34 @@ struct ExpandArgs {
 // maths.py:4-10 (python float %: result takes the sign of the divisor)
 __device__ __forceinline__ double normalize_angle(double th) {
     const double tau = 6.283185307179586, pi = 3.141592653589793;
-    th = fmod(th, tau);
+    if (!(fabs(th) < tau)) th = fmod(th, tau);       // |th| < tau: fmod returns th itself (exact); the sum of two headings is always there
     if (th < 0) th += tau;
     if (th >= tau) th = 0.0;
     if (th >= pi) th -= tau;
     return th;
 }
 
-__device__ __forceinline__ void expand_block(const ExpandArgs &a, unsigned block_in_segment) {
-    __shared__ double s_hp[EXP_MAX_ROWS * 3];
-    __shared__ double s_xy[EXP_MAX_PTS * 2];
-    __shared__ int32_t s_hoff[EXP_MAX_OBST + 1];
-    __shared__ int32_t s_toff[MPCX_MAX_PRIM + 1];
-    __shared__ double s_aabb[EXP_MAX_OBST * 4];
-    for (int i = threadIdx.x; i < a.n_obst * 4; i += blockDim.x) s_aabb[i] = a.aabb[i];
-    for (int i = threadIdx.x; i < a.n_rows * 3; i += blockDim.x) s_hp[i] = a.hp[i];
-    for (int i = threadIdx.x; i < a.n_pts * 2; i += blockDim.x) s_xy[i] = a.tmpl_xy[i];
-    for (int i = threadIdx.x; i <= a.n_obst; i += blockDim.x) s_hoff[i] = a.hp_off[i];
-    for (int i = threadIdx.x; i <= a.n_prim; i += blockDim.x) s_toff[i] = a.tmpl_off[i];
-    __syncthreads();
+struct ExpandTables {       // the search model's tables in LDS
+    double hp[EXP_MAX_ROWS * 3];
+    double xy[EXP_MAX_PTS * 2];
+    int32_t hoff[EXP_MAX_OBST + 1];
+    int32_t toff[MPCX_MAX_PRIM + 1];
+    double aabb[EXP_MAX_OBST * 4];
+};
 
+__device__ __forceinline__ void expand_stage(const ExpandArgs &a, ExpandTables &t) {
+    for (int i = threadIdx.x; i < a.n_obst * 4; i += blockDim.x) t.aabb[i] = a.aabb[i];
+    for (int i = threadIdx.x; i < a.n_rows * 3; i += blockDim.x) t.hp[i] = a.hp[i];
+    for (int i = threadIdx.x; i < a.n_pts * 2; i += blockDim.x) t.xy[i] = a.tmpl_xy[i];
+    for (int i = threadIdx.x; i <= a.n_obst; i += blockDim.x) t.hoff[i] = a.hp_off[i];
+    for (int i = threadIdx.x; i <= a.n_prim; i += blockDim.x) t.toff[i] = a.tmpl_off[i];
+    __syncthreads();
+}
+
+// the records block_in_segment * 256 .. + 255 (one thread each) against the staged tables
+__device__ __forceinline__ void expand_records(const ExpandArgs &a, const ExpandTables &t, unsigned block_in_segment) {
+    const double *s_hp = t.hp, *s_xy = t.xy, *s_aabb = t.aabb;
+    const int32_t *s_hoff = t.hoff, *s_toff = t.toff;
     const long long gid = (long long)block_in_segment * blockDim.x + threadIdx.x;
     const long long total = (long long)a.n_nodes * a.n_prim;
     if (gid >= total) return;
@@ -137,7 +145,23 @@ __device__ __forceinline__ void expand_block(const ExpandArgs &a, unsigned block
     a.collide[gid] = hit ? 1 : 0;
 }
 
+__device__ __forceinline__ void expand_block(const ExpandArgs &a, unsigned block_in_segment) {
+    __shared__ ExpandTables t;
+    expand_stage(a, t);
+    expand_records(a, t, block_in_segment);
+}
+
 __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) { expand_block(a, blockIdx.x); }
+
+// cos / sin of every node's heading, once per NODE: the records of a node (one per primitive) would otherwise each evaluate the
+// same double-precision sincos, ~150 of the ~1000 instructions of a record in a kernel that is bound by instruction issue
+__global__ __launch_bounds__(256) void node_cs_kernel(int n, const double *nodes, double *cs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    sincos(nodes[3 * (size_t)i + 2], &s, &c);
+    cs[2 * (size_t)i] = c; cs[2 * (size_t)i + 1] = s;
+}
 
 // several searches in one launch: segment s = the nodes of one search (its own obstacle / template tables and output ranges);
 // every block belongs to exactly one segment, so the LDS staging of expand_block is unchanged
@@ -276,6 +300,17 @@ extern "C" int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, 
     if (!m || n_nodes < 0 || !nodes || !nbr || !cost || !collide)
         return mpcx_fail(ctx, MPCX_E_INVALID, "expand_batch: null pointer or negative node count");
     if (n_nodes == 0) return MPCX_OK;
+    if (!nodes_cs && n_nodes >= 4096) {        // bulk expansion with device trigonometry: one sincos per node in front of the records
+        const size_t need = (size_t)n_nodes * 2 * sizeof(double);
+        if (need > ctx->cs_cap) {
+            if (ctx->cs) (void)hipFree(ctx->cs);
+            ctx->cs = nullptr; ctx->cs_cap = 0;
+            if (hipMalloc((void **)&ctx->cs, need) != hipSuccess) return mpcx_fail(ctx, MPCX_E_LAUNCH, "expand_batch: cannot allocate %zu bytes", need);
+            ctx->cs_cap = need;
+        }
+        hipLaunchKernelGGL(mpcx::node_cs_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, n_nodes, nodes, ctx->cs);
+        nodes_cs = ctx->cs;
+    }
     mpcx::ExpandArgs a{m->n_prim, m->n_obst, m->n_pts, m->n_rest, n_nodes, m->d_tmpl_off, m->d_rest_off,
                        m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_rest, m->d_aabb, nodes, nodes_cs, nbr, cost, collide};
     const long long total = (long long)n_nodes * m->n_prim;
