@@ -56,6 +56,9 @@ mpcx_ctx *mpcx_create(int32_t device, void *hip_stream) {
     c->tune_rows = 0;
     memset(c->loop_key, 0, sizeof c->loop_key);
     c->err[0] = 0;
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { mpcx_destroy(c); return nullptr; }
     return c;
 }
 
@@ -67,6 +70,9 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     if (ctx->order) (void)hipFree(ctx->order);
     if (ctx->multi) (void)hipFree(ctx->multi);
     if (ctx->cs) (void)hipFree(ctx->cs);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);

@@ -24,6 +24,8 @@ struct mpcx_ctx {
     size_t prev_cut_cap;
     int32_t *order;             // scratch: work-queue order built from the hint, and its two counters behind it
     size_t order_cap;
+    hipStream_t side = nullptr; // side stream of mpcx_mpc_prepare_batch: the warm-start rollout runs beside the window selection (fork / join by events)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double *cs = nullptr;       // scratch of mpcx_expand_batch: (cos, sin) of the nodes' headings
     size_t cs_cap = 0;
     void *multi;                // scratch of mpcx_expand_multi_batch (segment descriptors + block tables)

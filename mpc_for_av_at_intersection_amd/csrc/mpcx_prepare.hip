@@ -79,37 +79,42 @@ struct RollArgs {
     double *xbar;
 };
 
-__device__ __forceinline__ void rollout_thread(const RollArgs &a, int b) {
-    if (b >= a.B) return;
+// Rollout of 64 instances by one wavefront (lane = instance: the reference's operation order, one dependent chain of T x (sincos, tan,
+// divide) per instance), results staged in LDS and written as ONE contiguous run: the 64 instances' xbar rows are adjacent in memory
+// (64 x 4 x (T+1) doubles).  Until round 3 every lane stored its doubles straight to memory, 8 bytes at a 4 (T+1) x 8-byte lane stride,
+// each its own write transaction: 165 MB of write traffic for 45 MB of output.
+constexpr int ROLL_W_MAX = MPCX_T_MAX + 1;
+__global__ __launch_bounds__(64) void rollout_kernel(RollArgs a) {
+    __shared__ double s_x[64][4 * ROLL_W_MAX + 1];      // +1: rows of 4 W doubles would sit 8 lanes to a bank group
     const int T = a.p.T, W = T + 1;
-    double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2], th = a.state[4 * b + 3];
-    double *xb = a.xbar + (size_t)b * 4 * W;
-    xb[0] = x; xb[W] = y; xb[2 * W] = v; xb[3 * W] = th;
-    const double *oa = a.u_warm ? a.u_warm + (size_t)b * 2 * T : nullptr;
-    for (int t = 1; t <= T; t++) {
-        const double ai = oa ? oa[t - 1] : 0.0, di = oa ? oa[T + t - 1] : 0.0;   // mpc.py:222-224: zeros when no warm start
-        plant_step(a.p, x, y, v, th, ai, di);
-        xb[t] = x; xb[W + t] = y; xb[2 * W + t] = v; xb[3 * W + t] = th;
+    const int b0 = (int)blockIdx.x * 64;
+    const int n = a.B - b0 < 64 ? a.B - b0 : 64;
+    if (threadIdx.x < (unsigned)n) {
+        const int b = b0 + (int)threadIdx.x;
+        double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2], th = a.state[4 * b + 3];
+        double *xb = s_x[threadIdx.x];
+        xb[0] = x; xb[W] = y; xb[2 * W] = v; xb[3 * W] = th;
+        const double *oa = a.u_warm ? a.u_warm + (size_t)b * 2 * T : nullptr;
+        for (int t = 1; t <= T; t++) {
+            const double ai = oa ? oa[t - 1] : 0.0, di = oa ? oa[T + t - 1] : 0.0;   // mpc.py:222-224: zeros when no warm start
+            plant_step(a.p, x, y, v, th, ai, di);
+            xb[t] = x; xb[W + t] = y; xb[2 * W + t] = v; xb[3 * W + t] = th;
+        }
     }
+    __syncthreads();
+    double *out = a.xbar + (size_t)b0 * 4 * W;
+    for (int i = threadIdx.x; i < n * 4 * W; i += blockDim.x) out[i] = s_x[i / (4 * W)][i % (4 * W)];
 }
 
-// One launch for both halves of mpc.py:211-239's preparation: the first ceil(B/64) blocks roll the warm start out (one thread per
-// instance), the following B blocks select the reference window (one wavefront per instance).  The two are independent, and
-// the rollout is a chain of T dependent sincos/tan evaluations per thread, so running it BESIDE the window selection instead of
-// after it hides it completely.
-// Workgroups of four wavefronts (four instances' windows, or 256 rollouts): fewer, larger workgroups to dispatch (57 -> 54 us).
-// Alone, the window blocks take 31 us and the rollout blocks 44 (a chain of T x (sincos, tan, divide) on a lone lane per
-// instance: 6.5 k cycles per step); a rollout with the time steps on the lanes of a half wavefront (transcendentals in parallel,
-// only the carrying additions in sequence, bit-identical) was measured at 80 us for the launch: its 16 k extra wavefronts of
-// shuffle loops cost more than the hidden chain.
+// The two halves of mpc.py:211-239's preparation are independent -- the rollout is a chain of T dependent sincos / tan evaluations per
+// instance (44 us), the window selection a scan of the path (31 us) -- and run BESIDE each other: the rollout on the context's side
+// stream (fork / join by events, capturable into the closed loop's hipGraph), the window selection on the context's stream.  (Until
+// round 3 both were workgroups of one launch; the rollout's 68-KB staging buffer would have been allocated for every workgroup of it.)
+// Window workgroups of four wavefronts = four instances: fewer, larger workgroups to dispatch (57 -> 54 us).
 constexpr int PREP_WAVES = 4;
-__global__ __launch_bounds__(64 * PREP_WAVES) void prepare_kernel(RefArgs ra, RollArgs ro) {
-    const int nroll = (ro.B + 64 * PREP_WAVES - 1) / (64 * PREP_WAVES);          // the long-running rollout blocks are dispatched first
-    if ((int)blockIdx.x < nroll) rollout_thread(ro, (int)blockIdx.x * 64 * PREP_WAVES + threadIdx.x);
-    else {
-        const int b = ((int)blockIdx.x - nroll) * PREP_WAVES + (threadIdx.x >> 6);
-        if (b < ra.B) ref_window_block(ra, b);
-    }
+__global__ __launch_bounds__(64 * PREP_WAVES) void ref_window_kernel(RefArgs ra) {
+    const int b = (int)blockIdx.x * PREP_WAVES + (threadIdx.x >> 6);
+    if (b < ra.B) ref_window_block(ra, b);
 }
 
 struct PlantArgs {
@@ -183,8 +188,12 @@ extern "C" int32_t mpcx_mpc_prepare_batch_ov(mpcx_ctx *ctx, int32_t B, const dou
         return mpcx_fail(ctx, MPCX_E_INVALID, "mpc_prepare_batch_ov: ov_stride %lld is smaller than T + 1", (long long)ov_stride);
     mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end, ov, (long)ov_stride};
     mpcx::RollArgs ro{ctx->mpc, B, state, u_warm, xbar};
-    hipLaunchKernelGGL(mpcx::prepare_kernel, dim3((B + mpcx::PREP_WAVES - 1) / mpcx::PREP_WAVES + (B + 64 * mpcx::PREP_WAVES - 1) / (64 * mpcx::PREP_WAVES)),
-                       dim3(64 * mpcx::PREP_WAVES), 0, ctx->stream, ra, ro);
+    if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot fork the side stream");
+    hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->side, ro);
+    hipLaunchKernelGGL(mpcx::ref_window_kernel, dim3((B + mpcx::PREP_WAVES - 1) / mpcx::PREP_WAVES), dim3(64 * mpcx::PREP_WAVES), 0, ctx->stream, ra);
+    if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot join the side stream");
     return mpcx_check_launch(ctx, "prepare kernels");
 }
 

@@ -18,7 +18,7 @@ struct GroupCx {
     static constexpr bool JERK = JERK_;       // the five-state problem of lib/mpc_jerk.py (mpcx_mpc_params.model)
     static_assert(LQ == 4 || LQ == 8, "groups of 4 or 8 lanes");
     int q, lane;
-    lds_double *sh;                       // s [SPL*8][64], lam [SPL*8][64], gains [SPL*8][64]
+    lds_double *sh;                       // s [SPL*8][64], lam [SPL*8][64], gains [SPL*8][64], spare [2*SPL][64]
     // quad_perm [1,2,3,3] / [0,0,1,2] = value of lane q+1 / q-1; row_shl:1 / row_shr:1 do the same across a whole row.
     // The value arriving at a group's edge lane comes from the neighbouring group and is never used.
     __device__ __forceinline__ double nxt(double v) const { return LQ == 4 ? dpp_mov<0xF9>(v, v) : dpp_mov<0x101>(v, v); }
@@ -70,6 +70,8 @@ struct GroupCx {
     __device__ __forceinline__ void st_s(int k, double v) { sh[(0 * SPL * 8 + k) * 64 + lane] = v; }
     __device__ __forceinline__ void st_l(int k, double v) { sh[(1 * SPL * 8 + k) * 64 + lane] = v; }
     __device__ __forceinline__ void st_k(int k, double v) { sh[(2 * SPL * 8 + k) * 64 + lane] = v; }
+    __device__ __forceinline__ double ld_w(int k) const { return sh[(3 * SPL * 8 + k) * 64 + lane]; }     // per-problem constants (2 * SPL per lane)
+    __device__ __forceinline__ void st_w(int k, double v) { sh[(3 * SPL * 8 + k) * 64 + lane] = v; }
 };
 
 // work queue: group leaders draw problem indices from a global ticket until the batch is exhausted
@@ -112,7 +114,7 @@ struct QueueSrc {
 
 template <int LQ, int SPL, bool TUNED, bool JERK>
 __global__ __launch_bounds__(64, 1) void qp_quad_kernel(QpArgs a) {
-    __shared__ double sh[3 * SPL * 8 * 64];
+    __shared__ double sh[(3 * SPL * 8 + 2 * SPL) * 64];
     const int lane = threadIdx.x;
     GroupCx<LQ, SPL, JERK> cx{lane & (LQ - 1), lane, (lds_double *)sh};
     QueueSrc<LQ, SPL, TUNED> src{a};

@@ -98,7 +98,12 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
 
     // ------------------------------------------------------------------ per-slot constants and iterate
     double A0[SPL] = {}, A1[SPL] = {}, A2[SPL] = {}, A3[SPL] = {}, B3[SPL] = {};   // a02, a03, a12, a13, b3 of mpc.py:58-79 (delta_bar = 0)
-    double Wxx[SPL] = {}, Wxy[SPL] = {}, Wyy[SPL] = {};       // 2*W_{t+1} xy block (mpc.py:157-170)
+    // 2*W_{t+1} xy block (mpc.py:157-170): the off-diagonal entries in registers, the diagonal ones in the policy's spare row storage
+    // (cx.ld_w / cx.st_w, slots ls and SPL + ls): constants of a problem that are read three times per round -- the register
+    // allocator kept them in scratch (HBM-backed) anyway, at a memory round trip per Riccati sweep
+    double Wxy[SPL] = {};
+#define WXX(ls) cx.ld_w(ls)
+#define WYY(ls) cx.ld_w(SPL + (ls))
     bool ended[SPL] = {}, uend[SPL] = {};                     // x_{t+1} / u_t fall on the clipped tail of the reference (Qf / R_end)
     double U0[SPL] = {}, U1[SPL] = {};                        // a_t, delta_t
     // x_{t+1} as tracking error: X0, X1, X3 = (x, y, psi) - reference, X2 = v itself (the speed rows need it), XRV = reference speed.
@@ -238,7 +243,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         for (int ls = 0; ls < SPL; ls++) {
             const int t = q * SPL + ls;
             const double e0 = X0[ls], e1 = X1[ls], e2 = X2[ls] - XRV[ls], e3 = X3[ls];
-            G0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; G1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; G2[ls] = WV(ls) * e2; G3[ls] = WP(ls) * e3;
+            G0[ls] = WXX(ls) * e0 + Wxy[ls] * e1; G1[ls] = Wxy[ls] * e0 + WYY(ls) * e1; G2[ls] = WV(ls) * e2; G3[ls] = WP(ls) * e3;
             const bool has_next = act[ls] && (t + 1 < T);
             double g0 = (RA_(ls) + JW_(ls)) * U0[ls], g1 = RS_(ls) * U1[ls];
             if (rate[ls]) { g0 += Rda * (U0[ls] - Up0[ls]); g1 += Rds * (U1[ls] - Up1[ls]); }
@@ -310,15 +315,16 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             const double yr = act[ls] ? in_yr[ls] : 0.0;
             sincos(yr, &sn, &cs);
             // perpendicular projector [[s^2, -sc], [-sc, c^2]] * w_perp + parallel projector [[c^2, cs], [cs, s^2]] * w_para
-            Wxx[ls] = 2.0 * (ended[ls] ? P.Qf[0] : (sn * sn) * P.w_perp + (cs * cs) * P.w_para);
+            double wxx = 2.0 * (ended[ls] ? P.Qf[0] : (sn * sn) * P.w_perp + (cs * cs) * P.w_para);
             Wxy[ls] = 2.0 * (ended[ls] ? 0.0 : (-sn * cs) * P.w_perp + (cs * sn) * P.w_para);
-            Wyy[ls] = 2.0 * (ended[ls] ? P.Qf[1] : (cs * cs) * P.w_perp + (sn * sn) * P.w_para);
+            double wyy = 2.0 * (ended[ls] ? P.Qf[1] : (cs * cs) * P.w_perp + (sn * sn) * P.w_para);
             uend[ls] = in_uend[ls];
             U0[ls] = in_u0[ls];
             U1[ls] = in_u1[ls];
             // slots beyond the horizon (and groups beyond the batch) carry all-zero data: every sweep below passes through them
             // unchanged (zero dynamics, zero weights, rows off), so the code needs no per-slot branches
-            if (!act[ls]) { A0[ls] = A1[ls] = A2[ls] = A3[ls] = B3[ls] = 0.0; Wxx[ls] = Wxy[ls] = Wyy[ls] = 0.0; }
+            if (!act[ls]) { A0[ls] = A1[ls] = A2[ls] = A3[ls] = B3[ls] = 0.0; wxx = Wxy[ls] = wyy = 0.0; }
+            cx.st_w(ls, wxx); cx.st_w(SPL + ls, wyy);
             PH[ls] = ph;
         }
         Rda = 2.0 * P.Rd[0]; Rds = 2.0 * P.Rd[1];
@@ -336,7 +342,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             for (int ls = 0; ls < SPL; ls++) {
                 const double e0 = F0[ls] - in_r0[ls], e1 = F1[ls] - in_r1[ls];
                 const double e2 = F2[ls] - in_r2[ls], e3 = F3[ls] - in_yr[ls];
-                Q0[ls] = Wxx[ls] * e0 + Wxy[ls] * e1; Q1[ls] = Wxy[ls] * e0 + Wyy[ls] * e1; Q2[ls] = WV(ls) * e2; Q3[ls] = WP(ls) * e3;
+                Q0[ls] = WXX(ls) * e0 + Wxy[ls] * e1; Q1[ls] = Wxy[ls] * e0 + WYY(ls) * e1; Q2[ls] = WV(ls) * e2; Q3[ls] = WP(ls) * e3;
                 Z[ls] = 0.0;
             }
             const double gz = costate(Q0, Q1, Q2, Q3, Z, Z, O0, O1);
@@ -562,7 +568,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                             MPCX_UNROLL
                             for (int j = i; j < 7; j++) { Pf[i][j] = Pm[PX7(i, j)]; Pf[j][i] = Pf[i][j]; }
                         // 1. own state cost of x_{t+1} (+ speed barrier) and its gradient
-                        Pf[0][0] += Wxx[ls]; Pf[0][1] += Wxy[ls]; Pf[1][0] += Wxy[ls]; Pf[1][1] += Wyy[ls];
+                        Pf[0][0] += WXX(ls); Pf[0][1] += Wxy[ls]; Pf[1][0] += Wxy[ls]; Pf[1][1] += WYY(ls);
                         Pf[2][2] += WV(ls) + DSv[ls]; Pf[3][3] += WP(ls);
                         MPCX_UNROLL
                         for (int i = 0; i < 7; i++) g[i] = pv[i];
@@ -633,7 +639,7 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
                         // index of (i,j), i<=j, in the packed upper triangle of a 6x6
 #define PX(i, j) ((i) * 6 - (i) * ((i) + 1) / 2 + (j))
                         // 1. own state cost of x_{t+1} (+ speed barrier) and its gradient
-                        const double p00 = Pm[PX(0, 0)] + Wxx[ls], p01 = Pm[PX(0, 1)] + Wxy[ls], p11 = Pm[PX(1, 1)] + Wyy[ls];
+                        const double p00 = Pm[PX(0, 0)] + WXX(ls), p01 = Pm[PX(0, 1)] + Wxy[ls], p11 = Pm[PX(1, 1)] + WYY(ls);
                         const double p02 = Pm[PX(0, 2)], p03 = Pm[PX(0, 3)], p04 = Pm[PX(0, 4)], p05 = Pm[PX(0, 5)];
                         const double p12 = Pm[PX(1, 2)], p13 = Pm[PX(1, 3)], p14 = Pm[PX(1, 4)], p15 = Pm[PX(1, 5)];
                         const double p22 = Pm[PX(2, 2)] + WV(ls) + DSv[ls];
@@ -1055,6 +1061,8 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         cx.stamp(9);                    // [update]
     }
 #undef PX
+#undef WXX
+#undef WYY
 #undef WV
 #undef WP
 #undef RA_

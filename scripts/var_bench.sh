@@ -1,7 +1,8 @@
 #!/bin/bash
-# GPU box: headline bench (no extras) for each library variant build/libmpcx_<name>.so given on the command line
+# GPU box: headline bench (no extras) for each library variant build/libmpcx_<name>.so given on the command line ("tree" = the in-tree library)
 for v in "$@"; do
-  MPCX_LIB=build/libmpcx_$v.so python bench.py --no-extras --no-cpu > gpurun_out/vb_$v.log 2>&1
+  if [ "$v" = tree ]; then unset MPCX_LIB; else export MPCX_LIB=build/libmpcx_$v.so; fi
+  python bench.py --no-extras --no-cpu > gpurun_out/vb_$v.log 2>&1
   python - "$v" <<'PY'
 import json, sys
 v = sys.argv[1]

@@ -10,7 +10,7 @@ struct HostCx {
     static constexpr int LQ = 1, SPL = MPCX_T_MAX;
     static constexpr bool JERK = JERK_;
     int q = 0;
-    double s[SPL * 8], l[SPL * 8], k[SPL * 8];
+    double s[SPL * 8], l[SPL * 8], k[SPL * 8], w[2 * SPL];
     double prv(double v) const { return v; }
     double nxt(double v) const { return v; }
     double gmax(double v) const { return v; }
@@ -35,6 +35,8 @@ struct HostCx {
     void st_s(int k, double v) { s[k] = v; }
     void st_l(int k, double v) { l[k] = v; }
     void st_k(int j, double v) { k[j] = v; }
+    double ld_w(int j) const { return w[j]; }
+    void st_w(int j, double v) { w[j] = v; }
 };
 }  // namespace
 
