@@ -118,6 +118,37 @@ int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, int32_t n_n
                           const double *nodes_cs /*n,2: cos,sin of nodes[:,2], or NULL = device sincos*/,
                           double *nbr /*n,P,3*/, double *cost /*n,P*/, uint8_t *collide /*n,P*/);
 
+/* ---- lib/a_star.py:31-78 `AStar.run` + lib/motion_primitive_search.py:64-75,87-121 (is_goal, distance_to_goal, neighbor_function) and
+ * lib/motion_primitive_search_modified.py:80-89 for MANY independent searches, open list and closed set resident on the device: one
+ * wavefront per search, no host work between expansions.  The pop order is the reference's (tuples (g + h, g, node, predecessor)
+ * compared field by field, node identity = float equality), which needs the reference's bits in every number: cos / sin of a node's
+ * heading come from a table the host fills with numpy (cs_theta ascending, cs_val (cos, sin)): a heading missing from it ends the
+ * search with MPCX_ASTAR_MISS and the heading in buffers.miss; the `modified` heuristic squares with x * x where Python's ** is libm
+ * pow (one ulp apart for ~0.08 % of arguments), logs the h of every push, and takes corrections from an override table (hov_node sorted
+ * as tuples, hov_h) the host fills after checking the log with Python floats.  models / searches are HOST arrays; every pointer inside
+ * mpcx_astar_buffers is a DEVICE pointer to caller-owned memory: heap n x heap_cap x 10 doubles, table n x table_cap x 8 doubles
+ * FILLED WITH NaN (table_cap a power of two), log n x log_cap x 8 (node, g, h, predecessor per expansion: a_star.py:52), push_log
+ * n x push_cap x 4 (node, h per push), path n x path_cap x 3 and path_prim n x path_cap (goal first, primitive that led to each node,
+ * -1 at the start), cost / miss / status / n_exp / n_push / path_len n each. */
+enum { MPCX_ASTAR_BASE = 0, MPCX_ASTAR_MODIFIED = 1 };
+enum { MPCX_ASTAR_FOUND = 0, MPCX_ASTAR_EXHAUSTED = 1 /* "No solution found." */, MPCX_ASTAR_CAPACITY = 2, MPCX_ASTAR_MISS = 3 };
+typedef struct {
+    double start[3];
+    double goal_box[4];         /* BoxObstacle.xy1, xy2 of scenario.goal_area */
+    double goal_point[3];
+    double allowed_dtheta;      /* scenario.allowed_goal_theta_difference */
+    int32_t variant;            /* MPCX_ASTAR_BASE / MPCX_ASTAR_MODIFIED */
+    int32_t max_expansions;
+} mpcx_astar_search;
+typedef struct {
+    int32_t heap_cap, table_cap, log_cap, push_cap, path_cap;
+    double *heap, *table, *log, *push_log, *path, *cost, *miss;
+    int32_t *status, *n_exp, *n_push, *path_len, *path_prim;
+} mpcx_astar_buffers;
+int32_t mpcx_astar_batch(mpcx_ctx *ctx, int32_t n_search, const mpcx_search_model *const *models, const mpcx_astar_search *searches,
+                         int32_t n_cs, const double *cs_theta, const double *cs_val,
+                         int32_t n_hov, const double *hov_node, const double *hov_h, const mpcx_astar_buffers *buffers);
+
 /* ---- the same expansion for SEVERAL searches in one launch (many independent planners running concurrently): segment s = nodes
  * seg_off[s] .. seg_off[s+1]-1 of the node table (HOST array, n_seg+1 entries), expanded against models[s] (HOST array of
  * handles; all with the same number of primitives).  Outputs are laid out exactly as n_seg separate mpcx_expand_batch calls

@@ -40,6 +40,20 @@ class ClosedLoopC(C.Structure):
                 [('n_inst', C.c_int32), ('agents_local', C.c_int32), ('obs_local', C.c_void_p)])
 
 
+class AstarSearchC(C.Structure):
+    """mirror of mpcx_astar_search (include/mpcx.h)"""
+    _fields_ = [('start', C.c_double * 3), ('goal_box', C.c_double * 4), ('goal_point', C.c_double * 3), ('allowed_dtheta', C.c_double),
+                ('variant', C.c_int32), ('max_expansions', C.c_int32)]
+
+
+class AstarBuffersC(C.Structure):
+    """mirror of mpcx_astar_buffers (include/mpcx.h); every pointer is a device address"""
+    _fields_ = ([(n, C.c_int32) for n in ('heap_cap', 'table_cap', 'log_cap', 'push_cap', 'path_cap')] +
+                [(n, C.c_void_p) for n in ('heap', 'table', 'log', 'push_log', 'path', 'cost', 'miss', 'status', 'n_exp', 'n_push', 'path_len', 'path_prim')])
+
+
+ASTAR_BASE, ASTAR_MODIFIED = 0, 1
+ASTAR_FOUND, ASTAR_EXHAUSTED, ASTAR_CAPACITY, ASTAR_MISS = 0, 1, 2, 3
 COMM_ID_BYTES = 128
 SHARD_INSTANCES, SHARD_AGENTS = 1, 2
 
@@ -50,7 +64,7 @@ EXPORTS = ['mpcx_create', 'mpcx_destroy', 'mpcx_last_error', 'mpcx_version', 'mp
            'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch', 'mpcx_selftest_wave_ops', 'mpcx_selftest_mfma',
            'mpcx_closed_loop_run', 'mpcx_profile_qp', 'mpcx_profile_qp_read', 'mpcx_set_instance_tuning', 'mpcx_set_qp_solver', 'mpcx_qp_set_order_hint', 'mpcx_expand_multi_batch',
            'mpcx_comm_unique_id', 'mpcx_comm_init', 'mpcx_comm_destroy', 'mpcx_allgather_states', 'mpcx_closed_loop_stats',
-           'mpcx_mpc_prepare_batch_ov', 'mpcx_set_linearisation_passes']
+           'mpcx_mpc_prepare_batch_ov', 'mpcx_set_linearisation_passes', 'mpcx_astar_batch']
 
 
 def load():
@@ -76,6 +90,8 @@ def load():
     lib.mpcx_mpc_prepare_batch_ov.restype = i32
     lib.mpcx_mpc_prepare_batch_ov.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, C.c_double, vp, vp, C.c_int64, vp, vp, vp]
     lib.mpcx_set_linearisation_passes.restype = i32; lib.mpcx_set_linearisation_passes.argtypes = [vp, i32]
+    lib.mpcx_astar_batch.restype = i32
+    lib.mpcx_astar_batch.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.mpcx_search_model_create.restype = vp
     lib.mpcx_search_model_create.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.mpcx_search_model_destroy.restype = None; lib.mpcx_search_model_destroy.argtypes = [vp]

@@ -1,0 +1,337 @@
+// mpcx_astar.hip -- device-resident best-first search over motion primitives: the open list, the closed set and the successor
+// generation of MANY independent searches live on the GPU, one wavefront per search, no host work between expansions.
+//
+// Replaces (paths relative to /root/reference/main) lib/a_star.py:31-78 `AStar.run` together with
+// lib/motion_primitive_search.py:64-75,87-121 (is_goal, distance_to_goal, neighbor_function) and
+// lib/motion_primitive_search_modified.py:80-89 (the heuristic every stock MPC scenario uses).
+//
+// Exactness.  The reference's pop order is the order of the Python tuples (g + h, g, node, predecessor) and its node identity is
+// float equality of (x, y, theta), so every number that enters them must come out with the reference's bits:
+//  * successor coordinates need cos / sin of the node's heading as numpy computes them: they are LOOKED UP in a table the host
+//    fills with numpy (sorted by heading; the headings a search can reach are the closure of its start heading under the nine
+//    primitive heading changes, a few 10^5 values to the depth a search goes).  A heading that is not in the table ends the search with
+//    MPCX_ASTAR_MISS and the heading in `miss`: the host adds it and runs the search again;
+//  * g is a chain of float additions, the goal test and the `base` heuristic are +, -, *, max, abs and a correctly rounded sqrt:
+//    reproduced exactly with un-fused IEEE operations;
+//  * the `modified` heuristic squares with Python's `**`, i.e. libm pow(x, 2.0), which is NOT always the correctly rounded x * x (one ulp
+//    off for ~0.08 % of arguments).  The kernel uses x * x, logs the h of every push, the host re-evaluates them with Python
+//    floats and hands the few that differ back as an override table (sorted by node); the search is run again with it.
+// The heap is 8-ary so that a wavefront sifts with one level per memory round trip (children compared by eight lanes, minimum by
+// shuffles); keys are compared as the tuples are, field by field.
+#include "mpcx_expand_core.h"
+#include <vector>
+
+namespace mpcx {
+
+constexpr int HEAP_ARITY = 8;
+constexpr int HE = 10;      // doubles per heap entry: f, g, node[3], pred[3], primitive id, (pad)
+constexpr int TE = 8;       // doubles per closed-set entry: node[3], g, pred[3], primitive id
+
+struct AstarArgs {
+    ExpandArgs model;       // tables of this search's model (nodes / outputs unused)
+    mpcx_astar_search sp;
+};
+
+struct AstarIO {
+    int n_search;
+    const AstarArgs *searches;
+    int n_cs; const double *cs_theta, *cs_val;
+    int n_hov; const double *hov_node, *hov_h;
+    int heap_cap, table_cap, log_cap, push_cap, path_cap;
+    double *heap, *table, *log, *push_log, *path, *cost, *miss;
+    int32_t *status, *n_exp, *n_push, *path_len, *path_prim;
+};
+
+// (f, g, node, pred) < (f', g', node', pred') as Python compares the tuples
+__device__ __forceinline__ bool key_less(const double *a, const double *b) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (a[i] < b[i]) return true;
+        if (a[i] > b[i]) return false;
+    }
+    return false;
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long h) {
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33;
+    return h;
+}
+__device__ __forceinline__ unsigned long long node_hash(double x, double y, double t) {
+    // float equality is the reference's node identity: -0.0 and 0.0 are one key
+    const unsigned long long a = (unsigned long long)__double_as_longlong(x + 0.0), b = (unsigned long long)__double_as_longlong(y + 0.0),
+                             c = (unsigned long long)__double_as_longlong(t + 0.0);
+    return mix64(a ^ mix64(b ^ mix64(c)));
+}
+
+// closed set: open addressing, empty slots hold NaN in their first field (the caller fills the table with NaN).  Returns the slot of the
+// node, or the empty slot where it would go (found tells which), or -1 when the table is full.
+__device__ __forceinline__ int table_find(const double *tab, int cap, double x, double y, double t, bool &found) {
+    unsigned long long h = node_hash(x, y, t);
+    for (int probe = 0; probe < cap; probe++) {
+        const int slot = (int)((h + (unsigned long long)probe) & (unsigned long long)(cap - 1));
+        const double *e = tab + (size_t)slot * TE;
+        const double ex = e[0];
+        if (ex != ex) { found = false; return slot; }
+        if (ex == x && e[1] == y && e[2] == t) { found = true; return slot; }
+    }
+    found = false;
+    return -1;
+}
+
+// sorted table lookup (ascending doubles): index of v or -1
+__device__ __forceinline__ int sorted_find(const double *tab, int n, double v) {
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const double m = tab[mid];
+        if (m == v) return mid;
+        if (m < v) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+// override table of the heuristic: nodes sorted as tuples
+__device__ __forceinline__ int node_find(const double *tab, int n, double x, double y, double t) {
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const double *m = tab + 3 * (size_t)mid;
+        if (m[0] == x && m[1] == y && m[2] == t) return mid;
+        const bool less = m[0] < x || (m[0] == x && (m[1] < y || (m[1] == y && m[2] < t)));
+        if (less) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+// BoxObstacle.distance_to_point (obstacles.py:95-103): dx = max(x1 - x, 0, x - x2), ...; sqrt(dx*dx + dy*dy)
+// hipcc contracts a * b + c into an fma by default and its __dmul_rn / __dadd_rn are plain operators; the reference's Python floats round
+// every product.  Where a value's bits matter the product goes through an empty asm that makes it opaque to the contraction pass.
+__device__ __forceinline__ double mul_rn(double a, double b) { double r = a * b; asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ double box_distance(const double *box, double x, double y) {
+    const double dx = fmax(fmax(__dadd_rn(box[0], -x), 0.0), __dadd_rn(x, -box[2]));
+    const double dy = fmax(fmax(__dadd_rn(box[1], -y), 0.0), __dadd_rn(y, -box[3]));
+    return __dsqrt_rn(__dadd_rn(mul_rn(dx, dx), mul_rn(dy, dy)));
+}
+
+__device__ __forceinline__ double heuristic(const mpcx_astar_search &sp, double x, double y, double t) {
+    if (sp.variant == MPCX_ASTAR_BASE) {            // motion_primitive_search.py:71-75
+        const double dxy = box_distance(sp.goal_box, x, y);
+        const double dth = fmax(0.0, __dadd_rn(fabs(__dadd_rn(t, -sp.goal_point[2])), -sp.allowed_dtheta));
+        return __dadd_rn(dxy, mul_rn(2.7, dth));
+    }
+    // motion_primitive_search_modified.py:80-89 (x * x stands for Python's x ** 2: see the file header)
+    const double ex = __dadd_rn(x, -sp.goal_point[0]), ey = __dadd_rn(y, -sp.goal_point[1]);
+    const double dxy = __dsqrt_rn(__dadd_rn(mul_rn(ex, ex), mul_rn(ey, ey)));
+    const double ad = fabs(__dadd_rn(t, -sp.goal_point[2]));
+    const double alt = __dadd_rn(ad, -__ddiv_rn(sp.allowed_dtheta, 2.0));
+    const double dth = alt < ad ? alt : ad;          // Python's min(a, b): b only if b < a
+    return __dadd_rn(dxy, mul_rn(2.7, dth));
+}
+
+__global__ __launch_bounds__(64) void astar_kernel(AstarIO io) {
+    __shared__ ExpandTables t;
+    const int sidx = blockIdx.x, lane = threadIdx.x;
+    const AstarArgs sa = io.searches[sidx];
+    const ExpandArgs &a = sa.model;
+    const mpcx_astar_search &sp = sa.sp;
+    expand_stage(a, t);
+    double *heap = io.heap + (size_t)sidx * io.heap_cap * HE;
+    double *tab = io.table + (size_t)sidx * io.table_cap * TE;
+    double *log = io.log + (size_t)sidx * io.log_cap * 8;
+    double *plog = io.push_log + (size_t)sidx * io.push_cap * 4;
+    int n_heap = 0, n_exp = 0, n_push = 0, status = MPCX_ASTAR_EXHAUSTED;
+    double result_cost = 0.0, goal_node[3] = {0.0, 0.0, 0.0};
+
+    // q = [(0, 0, start, start)]
+    if (lane == 0) {
+        double *e = heap;
+        e[0] = 0.0; e[1] = 0.0; e[2] = sp.start[0]; e[3] = sp.start[1]; e[4] = sp.start[2];
+        e[5] = sp.start[0]; e[6] = sp.start[1]; e[7] = sp.start[2]; e[8] = -1.0; e[9] = 0.0;
+    }
+    n_heap = 1;
+    __syncthreads();
+
+    for (long guard = 0; guard < (long)io.heap_cap + 8; guard++) {      // every pass pops one entry: bounded by the pushes the heap can hold
+        if (n_heap == 0) { status = MPCX_ASTAR_EXHAUSTED; break; }
+        // ---------------------------------------------------------------- heappop: the root leaves, the last entry sifts down from the root
+        double top[HE];
+#pragma unroll
+        for (int i = 0; i < HE; i++) top[i] = heap[i];
+        n_heap--;
+        if (n_heap > 0) {
+            double mv[HE];
+#pragma unroll
+            for (int i = 0; i < HE; i++) mv[i] = heap[(size_t)n_heap * HE + i];
+            int pos = 0;
+            for (;;) {
+                const int c0 = pos * HEAP_ARITY + 1;
+                if (c0 >= n_heap) break;
+                // lanes 0..7 hold the children (entries beyond the heap: +inf keys), the smallest is found by three shuffle steps
+                const int ci = c0 + (lane & 7);
+                double ck[8];
+                const bool have = ci < n_heap;
+#pragma unroll
+                for (int i = 0; i < 8; i++) ck[i] = have ? heap[(size_t)ci * HE + i] : INFINITY;
+                int best = ci;
+#pragma unroll
+                for (int d = 1; d < 8; d <<= 1) {
+                    double ok[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) ok[i] = __shfl_xor(ck[i], d, WAVE);
+                    const int ob = __shfl_xor(best, d, WAVE);
+                    const bool take = key_less(ok, ck) || (!key_less(ck, ok) && ob < best);
+                    if (take) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) ck[i] = ok[i];
+                        best = ob;
+                    }
+                }
+                // every lane of an eight-lane group now holds the group's minimum; group 0 is the one that loaded real children
+                double bk[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) bk[i] = __shfl(ck[i], 0, WAVE);
+                best = __shfl(best, 0, WAVE);
+                if (!key_less(bk, mv)) break;
+                if (lane < HE) heap[(size_t)pos * HE + lane] = heap[(size_t)best * HE + lane];
+                __syncthreads();
+                pos = best;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < HE; i++) heap[(size_t)pos * HE + i] = mv[i];
+            }
+            __syncthreads();
+        }
+        const double g = top[1], nx = top[2], ny = top[3], nth = top[4];
+        // ---------------------------------------------------------------- seen before with a g at least as good: skip (a_star.py:45-49)
+        bool found;
+        const int slot = table_find(tab, io.table_cap, nx, ny, nth, found);
+        if (slot < 0) { status = MPCX_ASTAR_CAPACITY; break; }
+        if (found && g >= tab[(size_t)slot * TE + 3]) continue;
+        if (n_exp >= io.log_cap || n_exp >= sp.max_expansions) { status = MPCX_ASTAR_CAPACITY; break; }
+        if (lane == 0) {
+            double *lg = log + (size_t)n_exp * 8;               // node, g, h = f - g, predecessor (a_star.py:52)
+            lg[0] = nx; lg[1] = ny; lg[2] = nth; lg[3] = g; lg[4] = __dadd_rn(top[0], -g); lg[5] = top[5]; lg[6] = top[6]; lg[7] = top[7];
+            double *te = tab + (size_t)slot * TE;               // pred_dict[node] = g, predecessor (+ the primitive that led here)
+            te[0] = nx; te[1] = ny; te[2] = nth; te[3] = g; te[4] = top[5]; te[5] = top[6]; te[6] = top[7]; te[7] = top[8];
+        }
+        n_exp++;
+        __syncthreads();
+        // ---------------------------------------------------------------- goal test at pop time (motion_primitive_search.py:64-69: no angle wrapping)
+        if (box_distance(sp.goal_box, nx, ny) <= 1e-5 && fabs(__dadd_rn(nth, -sp.goal_point[2])) <= sp.allowed_dtheta) {
+            status = MPCX_ASTAR_FOUND; result_cost = g; goal_node[0] = nx; goal_node[1] = ny; goal_node[2] = nth;
+            break;
+        }
+        // ---------------------------------------------------------------- neighbours: lane k tests primitive k
+        const int ic = sorted_find(io.cs_theta, io.n_cs, nth);
+        if (ic < 0) { status = MPCX_ASTAR_MISS; if (lane == 0) io.miss[sidx] = nth; break; }
+        const double c = io.cs_val[2 * (size_t)ic], s = io.cs_val[2 * (size_t)ic + 1];
+        const bool rot_only = (nx == 0.0 && ny == 0.0);     // linalg.py:13-17
+        const double tx = rot_only ? 0.0 : nx, ty = rot_only ? 0.0 : ny;
+        bool hit = true;
+        double pose[3] = {0.0, 0.0, 0.0};
+        if (lane < a.n_prim) {
+            hit = primitive_collides(a, t, lane, tx, ty, c, s);
+            primitive_end_pose(a, lane, tx, ty, nth, c, s, pose);
+        }
+        bool overflow = false;
+        for (int k = 0; k < a.n_prim; k++) {                   // in the order the reference's neighbour generator yields
+            const bool free_k = __shfl((int)hit, k, WAVE) == 0;
+            const double sx = __shfl(pose[0], k, WAVE), sy = __shfl(pose[1], k, WAVE), sth = __shfl(pose[2], k, WAVE);
+            if (!free_k) continue;
+            const double ng = __dadd_rn(g, a.edge_cost[k]);      // neighbor_g = g + edge_value
+            bool seen;
+            const int sl = table_find(tab, io.table_cap, sx, sy, sth, seen);
+            if (sl < 0) { overflow = true; break; }
+            if (seen && !(ng < tab[(size_t)sl * TE + 3])) continue;
+            double h = heuristic(sp, sx, sy, sth);
+            if (io.n_hov > 0) {
+                const int ov = node_find(io.hov_node, io.n_hov, sx, sy, sth);
+                if (ov >= 0) h = io.hov_h[ov];
+            }
+            if (n_heap >= io.heap_cap || n_push >= io.push_cap) { overflow = true; break; }
+            if (lane == 0) { double *pl = plog + (size_t)n_push * 4; pl[0] = sx; pl[1] = sy; pl[2] = sth; pl[3] = h; }
+            n_push++;
+            // heappush: sift up from the end
+            double nk[HE] = {__dadd_rn(ng, h), ng, sx, sy, sth, nx, ny, nth, (double)k, 0.0};
+            int pos = n_heap++;
+            while (pos > 0) {
+                const int par = (pos - 1) / HEAP_ARITY;
+                double pk[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) pk[i] = heap[(size_t)par * HE + i];
+                if (!key_less(nk, pk)) break;
+                if (lane < HE) heap[(size_t)pos * HE + lane] = heap[(size_t)par * HE + lane];
+                __syncthreads();
+                pos = par;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < HE; i++) heap[(size_t)pos * HE + i] = nk[i];
+            }
+            __syncthreads();
+        }
+        if (overflow) { status = MPCX_ASTAR_CAPACITY; break; }
+    }
+
+    // ---------------------------------------------------------------- result: the path back through the predecessors (a_star.py:60-68), goal first
+    int plen = 0;
+    if (status == MPCX_ASTAR_FOUND && lane == 0) {
+        double *path = io.path + (size_t)sidx * io.path_cap * 3;
+        int32_t *pprim = io.path_prim + (size_t)sidx * io.path_cap;
+        double cx = goal_node[0], cy = goal_node[1], cth = goal_node[2];
+        for (; plen < io.path_cap; plen++) {
+            bool f;
+            const int sl = table_find(tab, io.table_cap, cx, cy, cth, f);
+            path[3 * plen] = cx; path[3 * plen + 1] = cy; path[3 * plen + 2] = cth;
+            pprim[plen] = (f && sl >= 0) ? (int32_t)tab[(size_t)sl * TE + 7] : -1;
+            if (!f || sl < 0) break;
+            if (cx == sp.start[0] && cy == sp.start[1] && cth == sp.start[2]) { plen++; break; }
+            const double *e = tab + (size_t)sl * TE;
+            cx = e[4]; cy = e[5]; cth = e[6];
+        }
+    }
+    if (lane == 0) {
+        io.status[sidx] = status; io.n_exp[sidx] = n_exp; io.n_push[sidx] = n_push; io.cost[sidx] = result_cost; io.path_len[sidx] = plen;
+    }
+}
+
+}  // namespace mpcx
+
+extern "C" int32_t mpcx_astar_batch(mpcx_ctx *ctx, int32_t n_search, const mpcx_search_model *const *models, const mpcx_astar_search *searches,
+                                    int32_t n_cs, const double *cs_theta, const double *cs_val,
+                                    int32_t n_hov, const double *hov_node, const double *hov_h,
+                                    const mpcx_astar_buffers *b) {
+    if (!ctx) return MPCX_E_INVALID;
+    if (n_search == 0) return MPCX_OK;
+    if (n_search < 0 || !models || !searches || !b || n_cs < 0 || (n_cs > 0 && (!cs_theta || !cs_val)) || n_hov < 0 || (n_hov > 0 && (!hov_node || !hov_h)))
+        return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: null table or negative count");
+    if (b->heap_cap < 16 || b->table_cap < 16 || (b->table_cap & (b->table_cap - 1)) || b->log_cap < 1 || b->push_cap < 1 || b->path_cap < 2 ||
+        !b->heap || !b->table || !b->log || !b->push_log || !b->path || !b->path_prim || !b->cost || !b->miss || !b->status || !b->n_exp || !b->n_push || !b->path_len)
+        return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: buffers missing, capacities too small or table_cap not a power of two");
+    std::vector<mpcx::AstarArgs> host((size_t)n_search);
+    for (int i = 0; i < n_search; i++) {
+        const mpcx_search_model *m = models[i];
+        if (!m) return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: search %d has no model", i);
+        if (m->n_prim > 64) return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: more than 64 primitives");
+        if (searches[i].variant != MPCX_ASTAR_BASE && searches[i].variant != MPCX_ASTAR_MODIFIED)
+            return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: search %d: variant must be MPCX_ASTAR_BASE or MPCX_ASTAR_MODIFIED", i);
+        host[i].model = mpcx::ExpandArgs{m->n_prim, m->n_obst, m->n_pts, m->n_rest, 0, m->d_tmpl_off, m->d_rest_off, m->d_tmpl_xy, m->d_last_pose,
+                                         m->d_edge_cost, m->d_rest, m->d_aabb, nullptr, nullptr, nullptr, nullptr, nullptr};
+        host[i].sp = searches[i];
+    }
+    const size_t need = host.size() * sizeof(mpcx::AstarArgs);
+    if (need > ctx->multi_cap) {
+        if (ctx->multi) (void)hipFree(ctx->multi);
+        ctx->multi = nullptr; ctx->multi_cap = 0;
+        if (hipMalloc((void **)&ctx->multi, need * 2) != hipSuccess) return mpcx_fail(ctx, MPCX_E_LAUNCH, "astar_batch: cannot allocate %zu bytes", need * 2);
+        ctx->multi_cap = need * 2;
+    }
+    if (hipMemcpyAsync(ctx->multi, host.data(), need, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)      // `host` goes out of scope
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "astar_batch: descriptor upload failed");
+    mpcx::AstarIO io{n_search, (const mpcx::AstarArgs *)ctx->multi, n_cs, cs_theta, cs_val, n_hov, hov_node, hov_h,
+                     b->heap_cap, b->table_cap, b->log_cap, b->push_cap, b->path_cap, b->heap, b->table, b->log, b->push_log, b->path, b->cost, b->miss,
+                     b->status, b->n_exp, b->n_push, b->path_len, b->path_prim};
+    hipLaunchKernelGGL(mpcx::astar_kernel, dim3(n_search), dim3(64), 0, ctx->stream, io);
+    return mpcx_check_launch(ctx, "astar_kernel");
+}

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from ._session import context
-from .a_star import AStar
+from .a_star import AStar, AStarDebugData
 from .trajectories import car_trajectory_to_collision_point_trajectories, resample_curve
 
 NodeType = Tuple[float, float, float]
@@ -275,3 +275,134 @@ def plan_many(searches: List[MotionPrimitiveSearch], debug=False):
     for s, (cost, path) in zip(searches, results):
         out.append((cost, path, s.path_to_full_trajectory(path)))
     return out
+
+
+# ------------------------------------------------------------------ device-resident searches (csrc/mpcx_astar.hip)
+_CLOSURES = {}
+
+
+def heading_closure(start_thetas, dthetas, depth: int) -> np.ndarray:
+    """Every heading a search can reach within `depth` primitives: the closure of the start headings under theta -> normalize_angle(dtheta +
+    theta) (transform_2d_pts adds the primitive's end heading to the node's, linalg.py:48-50; maths.py:4-10), evaluated with numpy float64
+    arithmetic, which is the reference's (np.mod has Python's float % semantics).  Sorted ascending."""
+    key = (tuple(sorted(set(float(t) for t in start_thetas))), tuple(float(d) for d in dthetas), int(depth))
+    if key in _CLOSURES:
+        return _CLOSURES[key]
+    tau = 2 * np.pi
+    seen = np.unique(np.asarray(start_thetas, dtype=np.float64))
+    frontier = seen
+    dth = np.asarray(dthetas, dtype=np.float64)
+    for _ in range(depth):
+        nxt = np.mod(dth[None, :] + frontier[:, None], tau).ravel()
+        nxt = np.where(nxt >= np.pi, nxt - tau, nxt)
+        nxt = np.unique(nxt)
+        frontier = np.setdiff1d(nxt, seen, assume_unique=True)
+        if frontier.size == 0:
+            break
+        seen = np.union1d(seen, frontier)
+    _CLOSURES[key] = seen
+    return seen
+
+
+def plan_many_device(searches: List['MotionPrimitiveSearch'], max_expansions: int = 4096, closure_depth: int = 16, max_rounds: int = 6, debug=False):
+    """Run independent searches with open list, closed set and successor generation RESIDENT ON THE DEVICE (mpcx_astar_batch: one
+    wavefront per search, no host work between expansions) and the reference's exact pop order.  The host's part is what must carry the
+    reference's bits and cannot be evaluated on the device: the cos / sin table (numpy, over the closure of the start headings) before
+    the launch, and afterwards a check of every heuristic value the searches used against Python-float arithmetic (`**` is libm pow:
+    one ulp from x * x for ~0.08 % of arguments): values that differ go into an override table and the searches concerned run again --
+    typically one extra launch for a few of the searches.  Variants 'base' and 'modified' with box goal areas; anything else raises.
+    Returns ([(cost, path, trajectory), ...], info) with info = dict(launches, rounds per search, overrides, expansions)."""
+    from .. import _lib
+    if not searches:
+        return [], dict(launches=0)
+    ctx = searches[0]._ctx
+    for s in searches:
+        if s.variant not in ('base', 'modified'):
+            raise NotImplementedError("plan_many_device: variant %r (only 'base' and 'modified' run on the device)" % (s.variant,))
+        if not hasattr(s._goal_area, 'xy1'):
+            raise NotImplementedError('plan_many_device: the goal area must be a box')
+    import time as _time
+    t_start = _time.perf_counter()
+    dth = [float(searches[0]._mps[n].points[-1][2]) for n in searches[0]._names]
+    theta_tab = heading_closure([s._start[2] for s in searches], dth, closure_depth)
+    specs = [dict(start=s._start, goal_box=(*s._goal_area.xy1, *s._goal_area.xy2), goal_point=s._goal_point,
+                  allowed_dtheta=s._allowed_goal_theta_difference, variant=_lib.ASTAR_BASE if s.variant == 'base' else _lib.ASTAR_MODIFIED)
+             for s in searches]
+    overrides = {}                    # node -> h with the reference's bits
+    results = [None] * len(searches)
+    todo = list(range(len(searches)))
+    info = dict(launches=0, rounds=[0] * len(searches), overrides=0, expansions=[0] * len(searches), table_headings=int(theta_tab.size),
+                t_closure=_time.perf_counter() - t_start, t_device=0.0, t_check=0.0)
+    cs_t = cs_v = None
+    for _ in range(max_rounds):
+        if not todo:
+            break
+        if cs_t is None:
+            cs_t = ctx.f64(theta_tab)
+            cs_v = ctx.f64(np.column_stack([np.cos(theta_tab), np.sin(theta_tab)]))
+        hov_n = hov_h = None
+        if overrides:
+            keys = sorted(overrides)
+            hov_n, hov_h = ctx.f64(np.array(keys, dtype=np.float64).reshape(-1, 3)), ctx.f64(np.array([overrides[k] for k in keys]))
+        t0 = _time.perf_counter()
+        out = ctx.astar_batch([searches[i]._model for i in todo], [specs[i] for i in todo], cs_t, cs_v, hov_n, hov_h, max_expansions=max_expansions)
+        ctx.synchronize()
+        info['t_device'] += _time.perf_counter() - t0
+        t0 = _time.perf_counter()
+        info['launches'] += 1
+        status = out['status'].cpu().numpy(); n_exp = out['n_exp'].cpu().numpy(); n_push = out['n_push'].cpu().numpy()
+        path_len = out['path_len'].cpu().numpy(); costs = out['cost'].cpu().numpy(); misses = out['miss'].cpu().numpy()
+        # the pushes of all searches in one copy (variable-length rows)
+        push_rows = [out['push_log'][j, :int(n_push[j])] for j in range(len(todo))]
+        push_all = torch.cat(push_rows).cpu().numpy() if push_rows else np.zeros((0, 4))
+        push_off = np.concatenate([[0], np.cumsum(n_push)]).astype(np.int64)
+        again, new_thetas = [], []
+        for j, i in enumerate(todo):
+            s = searches[i]
+            info['rounds'][i] += 1
+            info['expansions'][i] = int(n_exp[j])
+            if status[j] == _lib.ASTAR_MISS:
+                new_thetas.append(float(misses[j]))
+                again.append(i)
+                continue
+            if status[j] == _lib.ASTAR_CAPACITY:
+                raise RuntimeError('plan_many_device: search %d exceeds %d expansions' % (i, max_expansions))
+            # the heuristic values the search used, against the reference's arithmetic (Python floats)
+            pl = push_all[push_off[j]:push_off[j + 1]]
+            bad = 0
+            if s.variant != 'base' and len(pl):
+                # motion_primitive_search_modified.py:80-89 with Python-float squares (`**` = libm pow); everything else is IEEE arithmetic that
+                # numpy evaluates identically, so only the squares are taken element by element
+                gx, gy, gth = s._goal_point
+                ex, ey = pl[:, 0] - gx, pl[:, 1] - gy
+                sq = np.array([v ** 2 for v in ex.tolist()]) + np.array([v ** 2 for v in ey.tolist()])
+                ad = np.abs(pl[:, 2] - gth)
+                ref = np.sqrt(sq) + 2.7 * np.minimum(ad, ad - s._allowed_goal_theta_difference / 2)
+                for r in np.nonzero(ref != pl[:, 3])[0]:
+                    overrides[(float(pl[r, 0]), float(pl[r, 1]), float(pl[r, 2]))] = float(ref[r])
+                    bad += 1
+            if bad:
+                again.append(i)
+                continue
+            if status[j] == _lib.ASTAR_EXHAUSTED:
+                raise Exception("No solution found.")
+            n = int(path_len[j])
+            nodes = out['path'][j, :n].cpu().numpy()[::-1]
+            prims = out['path_prim'][j, :n].cpu().numpy()[::-1]
+            path = [tuple(float(v) for v in p) for p in nodes]
+            for a, b, k in zip(path[:-1], path[1:], prims[1:]):
+                s._points_to_mp_names[a, b] = s._names[int(k)]
+            s.visited_nodes = int(n_exp[j])
+            if debug:
+                lg = out['log'][j, :int(n_exp[j])].cpu().numpy()
+                s._a_star._debug_data = [AStarDebugData(g=float(r[3]), h=float(r[4]), node=tuple(map(float, r[0:3])), predecessor=tuple(map(float, r[5:8]))) for r in lg]
+            results[i] = (float(costs[j]), path)
+        if new_thetas:      # headings beyond the closure: add them and what is reachable from them
+            theta_tab = np.union1d(theta_tab, heading_closure(new_thetas, dth, 4))
+            cs_t = None
+        info['t_check'] += _time.perf_counter() - t0
+        info['overrides'] = len(overrides)
+        todo = again
+    if todo:
+        raise RuntimeError('plan_many_device: %d searches did not settle in %d rounds' % (len(todo), max_rounds))
+    return [(c, p, s.path_to_full_trajectory(p)) for s, (c, p) in zip(searches, results)], info

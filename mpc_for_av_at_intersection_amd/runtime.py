@@ -250,6 +250,45 @@ class Context:
         return out
 
     @_ordered
+    def astar_batch(self, models, specs, cs_theta, cs_val, hov_node=None, hov_h=None, max_expansions=4096, path_cap=64):
+        """mpcx_astar_batch: one device-resident best-first search per entry of `specs` (dicts: start, goal_box, goal_point,
+        allowed_dtheta, variant) against models[i]; cs_theta (ascending) / cs_val: the host's cos / sin table; hov_node / hov_h: the
+        heuristic's override table (nodes sorted as tuples).  Returns a dict of device tensors: status, n_exp, n_push, cost, miss,
+        path_len, path (n, path_cap, 3; goal first), path_prim, log (n, max_expansions, 8), push_log (n, push_cap, 4)."""
+        n = len(specs)
+        f, dev = torch.float64, self.device
+        P = models[0].n_prim
+        heap_cap = max(16, P * max_expansions + 1)
+        table_cap = 1 << int(np.ceil(np.log2(2 * (max_expansions + 1))))
+        out = dict(heap=torch.empty((n, heap_cap, 10), dtype=f, device=dev), table=torch.full((n, table_cap, 8), float('nan'), dtype=f, device=dev),
+                   log=torch.zeros((n, max_expansions, 8), dtype=f, device=dev), push_log=torch.zeros((n, heap_cap, 4), dtype=f, device=dev),
+                   path=torch.zeros((n, path_cap, 3), dtype=f, device=dev), path_prim=torch.zeros((n, path_cap), dtype=torch.int32, device=dev),
+                   cost=torch.zeros(n, dtype=f, device=dev), miss=torch.zeros(n, dtype=f, device=dev),
+                   status=torch.zeros(n, dtype=torch.int32, device=dev), n_exp=torch.zeros(n, dtype=torch.int32, device=dev),
+                   n_push=torch.zeros(n, dtype=torch.int32, device=dev), path_len=torch.zeros(n, dtype=torch.int32, device=dev))
+        b = _lib.AstarBuffersC()
+        b.heap_cap, b.table_cap, b.log_cap, b.push_cap, b.path_cap = heap_cap, table_cap, max_expansions, heap_cap, path_cap
+        for k in ('heap', 'table', 'log', 'push_log', 'path', 'cost', 'miss', 'status', 'n_exp', 'n_push', 'path_len', 'path_prim'):
+            setattr(b, k, out[k].data_ptr())
+        sp = (_lib.AstarSearchC * n)()
+        for i, s in enumerate(specs):
+            sp[i].start[:] = [float(v) for v in s['start']]
+            sp[i].goal_box[:] = [float(v) for v in s['goal_box']]
+            sp[i].goal_point[:] = [float(v) for v in s['goal_point']]
+            sp[i].allowed_dtheta = float(s['allowed_dtheta'])
+            sp[i].variant = int(s['variant'])
+            sp[i].max_expansions = int(max_expansions)
+        hs = (C.c_void_p * n)(*[m._h for m in models])
+        self._want(cs_theta, f, None, 'cs_theta'); self._want(cs_val, f, (cs_theta.shape[0], 2), 'cs_val')
+        n_hov = 0 if hov_node is None else int(hov_node.shape[0])
+        if n_hov:
+            self._want(hov_node, f, (n_hov, 3), 'hov_node'); self._want(hov_h, f, (n_hov,), 'hov_h')
+        self._chk(self.lib.mpcx_astar_batch(self._ctx, n, hs, sp, int(cs_theta.shape[0]), _ptr(cs_theta), _ptr(cs_val),
+                                            n_hov, _ptr(hov_node) if n_hov else None, _ptr(hov_h) if n_hov else None, C.byref(b)))
+        del out['heap'], out['table']
+        return out
+
+    @_ordered
     def expand_multi(self, models, seg_off, nodes, nodes_cs=None):
         """mpcx_expand_multi_batch: nodes (n,3) grouped by search, seg_off = n_seg+1 offsets (host ints), models = one
         SearchModel per segment.  Returns dict(nbr (n,P,3), cost (n,P), collide (n,P)) laid out like separate expand() calls."""
