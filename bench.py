@@ -32,16 +32,18 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix rate (datasheet; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md chip table
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_final.csv')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_final.csv')
 
 
-def qp_flops_condensed(T: int, iters: float, trial: float = 1.0) -> float:
-    """algorithmic (structure-exploiting, condensed) FP64 flops of one agent-QP.  Every QP also runs the
-    trial pass of round 2 (one factorisation of H, ONE solve, one product with G -- against two solves and four products in an
-    interior-point iteration); `iters` counts interior-point iterations only (0 for a QP the trial pass solves)."""
+def qp_flops_condensed(T: int, iters: float, extra_passes: float = 0.0) -> float:
+    """algorithmic (structure-exploiting, condensed) FP64 flops of one agent-QP,
+    F_qp = 16/3 T^3 + 16 T^2 + K (n^3/3 + 4 n^2 + 6 T^2 + 12 m) with `iters` = K interior-point iterations (0 for a QP the trial pass
+    solves).  extra_passes = the passes that formula does not know, each ONE factorisation, ONE solve and one product with G (against
+    two solves and four products in an iteration): the trial pass every QP runs since round 2 and the active-set polish passes of the
+    constrained QPs since round 3."""
     n, m = 2 * T, 8 * T
     return ((16.0 / 3.0) * T ** 3 + 16.0 * T ** 2 + iters * (n ** 3 / 3.0 + 4.0 * n ** 2 + 6.0 * T ** 2 + 12.0 * m)
-            + trial * (n ** 3 / 3.0 + 2.0 * n ** 2 + 3.0 * T ** 2 + 4.0 * m))
+            + extra_passes * (n ** 3 / 3.0 + 2.0 * n ** 2 + 3.0 * T ** 2 + 4.0 * m))
 
 
 def qp_flops_stage(T: int, iters: float) -> float:
@@ -278,8 +280,14 @@ def main():
         or os.environ.get('MPCX_QP_KERNEL') == 'stage'
     # SURVEY 8(d)'s algorithmic count F_qp is the one the roofline is priced with (rounds stay comparable); the stage solver's own
     # need, counted on its source, is reported beside it
-    flops_qp = qp_flops_condensed(T, mean_iters)
+    trial_frac = float(((sim.sol['iters'] == 0) & (sim.sol['status'] == 0)).double().mean().item())
+    # passes beside the iterations: the trial pass of every QP + the polish passes of the constrained ones (1.07 per constrained QP on the
+    # benchmark workload: 7 % need a second pass)
+    extra_passes = 1.0 + 1.07 * (1.0 - trial_frac)
+    flops_survey = qp_flops_condensed(T, mean_iters)                      # SURVEY 8(d)'s formula as written
+    flops_qp = qp_flops_condensed(T, mean_iters, extra_passes)           # + the trial / polish passes
     achieved_tf = flops_qp * P_rank / (qp_ms * 1e-3) / 1e12
+    survey_tf = flops_survey * P_rank / (qp_ms * 1e-3) / 1e12
     own_tf = (qp_flops_stage(T, mean_iters) if stage else flops_qp) * P_rank / (qp_ms * 1e-3) / 1e12
     line = {
         'metric': 'MPC timesteps/sec (whole node), N=20 horizon, 8-agent intersection, batch=4096',
@@ -292,9 +300,11 @@ def main():
                    'instances_total': args.batch, 'instances_per_gpu': hi - lo, 'agents': A, 'horizon': T,
                    'parallelism': 'instances sharded over %d GPU(s), no data-path collective' % world},
         'agent_qp_per_s': value * A, 'mean_ipm_iters': mean_iters, 'max_ipm_iters': max_iters, 'qp_failures': int(failures),
-        'qp_solved_by_trial_pass': float(((sim.sol['iters'] == 0) & (sim.sol['status'] == 0)).double().mean().item()),
+        'qp_solved_by_trial_pass': trial_frac,
         'roofline': {'bound': 'fp64_valu', 'achieved': achieved_tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved_tf / FP64_PEAK_TFLOPS,
+                     'achieved_survey_formula': survey_tf, 'frac_survey_formula': survey_tf / FP64_PEAK_TFLOPS,
+                     'flops_per_qp_survey_formula': flops_survey, 'extra_passes_per_qp': extra_passes,
                      'traffic': pmc_traffic_bytes() if (T == 20 and P_rank == 32768) else None,
                      'algorithmic_bytes_per_launch': qp_launch_bytes(T, P_rank),
                      'traffic_note': 'HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from the committed rocprofv3 PMC passes (%s), same workload' % os.path.relpath(PMC_FILE, ROOT),
@@ -304,8 +314,10 @@ def main():
                      'executed_pmc': None,
                      'achieved_stage_count': own_tf, 'frac_stage_count': own_tf / FP64_PEAK_TFLOPS,
                      'note': 'mean_ipm_iters counts interior-point iterations; since round 2 every QP first runs a trial pass (unconstrained minimiser, accepted '
-                             'when it violates no row: qp_solved_by_trial_pass of the QPs end there with 0 iterations), counted in the flops as one '
-                             'factorisation + one solve.  The launch is bound by its slowest problems (max iterations x time per round), not by the mean.  '
+                             'when it violates no row: qp_solved_by_trial_pass of the QPs end there with 0 iterations), and since round 3 every constrained QP '
+                             'ends with an active-set polish pass (exact minimiser instead of a sqrt(mu)-accurate iterate; fewer iterations): both are counted '
+                             'as one factorisation + one solve each in `achieved` / `frac`; `*_survey_formula` is SURVEY 8(d)\'s F_qp(T, K) as written, '
+                             'without those passes.  The launch is bound by its slowest wavefront (queue imbalance + max iterations x time per round), not by the mean.  '
                              'The kernel is pure FP64 VALU (SQ_INSTS_MFMA = 0): roof = FP64 vector rate 78.6 TFLOP/s.  achieved = SURVEY 8(d)\'s '
                              'algorithmic count F_qp(T, measured mean iterations) + the trial pass, x QPs per launch / HIP-event kernel time on the '
                              'launch stream (the count rounds 1 and 2 are compared by).  *_stage_count = the same with the flops the stage '
@@ -344,7 +356,7 @@ def main():
                 big = synthetic_batch(ctx, B=Bbig, A=A, T=T, seed=1000, routes=routes, dl=dl, cd=cd)
                 big.run(args.burn_in + args.warmup)
                 el, it, fl, ms, _ = timed(big, args.steps)
-                fq = qp_flops_condensed(T, it / (Bbig * A * args.steps))
+                fq = qp_flops_condensed(T, it / (Bbig * A * args.steps), extra_passes)
                 line['work_bound'] = {'instances': Bbig, 'value': Bbig * args.steps / el, 'unit': 'MPC timesteps/s', 'ms_per_step': 1e3 * el / args.steps,
                                       'kernel_ms': ms, 'mean_ipm_iters': it / (Bbig * A * args.steps), 'qp_failures': int(fl),
                                       'frac': fq * Bbig * A / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
@@ -419,6 +431,37 @@ def main():
                                       'cost WITHOUT early-outs (every point x row test); it can exceed 1 because exact box culling skips most tests' % reps}
         except Exception as e:
             line['expand'] = {'error': repr(e)}
+        # -------------------------------------------------------------- device-resident A* (SURVEY 8(f)-2): 1024 searches in one launch
+        try:
+            if world == 1:
+                from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions
+                from mpc_for_av_at_intersection_amd.lib.motion_primitive import load_motion_primitives
+                from mpc_for_av_at_intersection_amd.lib.motion_primitive_search import MotionPrimitiveSearch, plan_many, plan_many_device
+                from mpc_for_av_at_intersection_amd.lib.scenario import intersection
+                cdb, mpsb = BicycleModelDimensions(), load_motion_primitives('bicycle_model')
+                pairs = [(sp, ti) for sp in (1, 2, 3, 4) for ti in (1, 2, 3)]
+                mk = lambda n: [MotionPrimitiveSearch(intersection(turn_indicator=pairs[i % 12][1], start_pos=pairs[i % 12][0]), cdb, mpsb, margin=cdb.radius,
+                                                      variant='modified', ctx=ctx) for i in range(n)]
+                plan_many_device(mk(12))               # warm-up: module load, heading table
+                ss = mk(1024)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                res, inf = plan_many_device(ss)
+                torch.cuda.synchronize(); t_dev = time.perf_counter() - t0
+                hs = mk(12)
+                t0 = time.perf_counter()
+                href = plan_many(hs)
+                t_host = time.perf_counter() - t0
+                same = all(res[i][0] == href[i][0] and res[i][1] == href[i][1] for i in range(12))
+                line['device_search'] = {'searches': 1024, 'ms_total': 1e3 * t_dev, 'ms_device': 1e3 * inf['t_device'], 'launches': inf['launches'],
+                                         'heuristic_overrides': inf['overrides'], 'expansions_total': int(sum(inf['expansions'])),
+                                         'host_queue_ms_for_12': 1e3 * t_host, 'host_queue_ms_scaled_to_1024': 1e3 * t_host * 1024 / 12,
+                                         'same_cost_and_path_as_host_search': bool(same),
+                                         'note': 'mpcx_astar_batch: the 12 stock routes (`modified` heuristic) replicated to 1024 independent searches, open list + closed set + '
+                                                 'successor generation resident on the device, one wavefront per search, the reference\'s pop order (golden runs replayed node '
+                                                 'for node in tests/test_gpu_astar.py); ms_total includes the host side (cos/sin table, check of the heuristic values against '
+                                                 'Python floats, result copies and 1024 trajectory assemblies); host_queue_* = plan_many (exact host queues + batched expansion)'}
+        except Exception as e:
+            line['device_search'] = {'error': repr(e)}
         # the two multi-rank extras create a second communicator and a second batch: a rank that fails inside one of them would
         # leave the others waiting in a collective, so a watchdog on every rank gives them a deadline, after which rank 0 prints
         # the line it has (headline + the extras already measured) and every rank leaves

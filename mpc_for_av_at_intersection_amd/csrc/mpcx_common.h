@@ -26,6 +26,7 @@ struct mpcx_ctx {
     size_t order_cap;
     hipStream_t side = nullptr; // side stream of mpcx_mpc_prepare_batch: the warm-start rollout runs beside the window selection (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool rollout_forked = false; // mpcx_closed_loop_run has the rollout of this step in flight on the side stream (mpcx_rollout_fork)
     double *cs = nullptr;       // scratch of mpcx_expand_batch: (cos, sin) of the nodes' headings
     size_t cs_cap = 0;
     void *multi;                // scratch of mpcx_expand_multi_batch (segment descriptors + block tables)
@@ -48,6 +49,7 @@ struct mpcx_ctx {
 int32_t mpcx_fail(mpcx_ctx *ctx, int32_t code, const char *fmt, ...);
 int32_t mpcx_check_launch(mpcx_ctx *ctx, const char *what);
 int32_t mpcx_ensure_pred(mpcx_ctx *ctx, size_t need_doubles);   // prediction scratch (mpcx_interaction.hip)
+int32_t mpcx_rollout_fork(mpcx_ctx *ctx, int32_t B, const double *state, const double *u_warm, double *xbar);   // mpcx_prepare.hip
 int32_t mpcx_ensure_ticket(mpcx_ctx *ctx);                      // work-queue word (mpcx_qp.hip)
 int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B);             // work-queue order scratch (mpcx_qp.hip)
 

@@ -34,6 +34,11 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
     if (hipMemcpyAsync(ctx->prev_cut, c->cut_len, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipMemcpyAsync failed");
     int32_t rc, pool_rows = P;
+    // the warm-start rollout of this step needs only the states and the previous solution: it runs on the side stream BESIDE the pool pack,
+    // the prediction and the conflict search (a chain of T dependent sincos / tan per agent, 35-45 us) and is joined by the window selection
+    rc = mpcx_rollout_fork(ctx, P, c->state, c->u_sol, c->xbar);
+    if (rc != MPCX_OK) return rc;
+    ctx->rollout_forked = true;
     if (c->exchange == MPCX_SHARD_AGENTS) {
         // agent-sharded layout: this rank's rows travel to every rank, every rank assembles the whole pool (one RCCL all-gather)
         mpcx::PackArgs pa{P, c->state, c->applied, c->obs_local};
@@ -122,6 +127,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     if (!use_graph) {
         for (int s = 0; s < n_steps; s++) {
             rc = enqueue_step(ctx, ip, c);
+        ctx->rollout_forked = false;
             if (rc != MPCX_OK) return rc;
         }
         return MPCX_OK;
@@ -155,6 +161,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
         if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
             return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipStreamBeginCapture failed");
         rc = enqueue_step(ctx, ip, c);
+        ctx->rollout_forked = false;
         hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
         if (rc != MPCX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess || !graph) return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: stream capture failed: %s", hipGetErrorString(e));

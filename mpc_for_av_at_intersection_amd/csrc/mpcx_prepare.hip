@@ -187,14 +187,27 @@ extern "C" int32_t mpcx_mpc_prepare_batch_ov(mpcx_ctx *ctx, int32_t B, const dou
     if (ov && ov_stride < (int64_t)ctx->mpc.T + 1)
         return mpcx_fail(ctx, MPCX_E_INVALID, "mpc_prepare_batch_ov: ov_stride %lld is smaller than T + 1", (long long)ov_stride);
     mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end, ov, (long)ov_stride};
-    mpcx::RollArgs ro{ctx->mpc, B, state, u_warm, xbar};
-    if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0) != hipSuccess)
-        return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot fork the side stream");
-    hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->side, ro);
+    // the rollout may already be in flight: mpcx_closed_loop_run forks it at the start of the step, beside the conflict search
+    const bool forked = ctx->rollout_forked;
+    ctx->rollout_forked = false;
+    if (!forked) {
+        int32_t rc = mpcx_rollout_fork(ctx, B, state, u_warm, xbar);
+        if (rc != MPCX_OK) return rc;
+    }
     hipLaunchKernelGGL(mpcx::ref_window_kernel, dim3((B + mpcx::PREP_WAVES - 1) / mpcx::PREP_WAVES), dim3(64 * mpcx::PREP_WAVES), 0, ctx->stream, ra);
     if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot join the side stream");
     return mpcx_check_launch(ctx, "prepare kernels");
+}
+
+// the warm-start rollout (mpc.py:112-126 `_predict_motion`) on the context's side stream, ordered behind everything enqueued on the
+// context's stream so far; the next mpcx_mpc_prepare_batch[_ov] joins it instead of launching its own
+int32_t mpcx_rollout_fork(mpcx_ctx *ctx, int32_t B, const double *state, const double *u_warm, double *xbar) {
+    mpcx::RollArgs ro{ctx->mpc, B, state, u_warm, xbar};
+    if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot fork the side stream");
+    hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->side, ro);
+    return MPCX_OK;
 }
 
 extern "C" int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state, double *u,

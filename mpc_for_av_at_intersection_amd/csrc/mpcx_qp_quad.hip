@@ -5,6 +5,7 @@
 // live in LDS as [row][lane] (conflict-free, 36 KB per workgroup at SPL = 3 = four workgroups per CU), everything else in
 // registers.  Wavefronts are persistent: groups draw problems from a global ticket (QueueSrc).
 #include "mpcx_common.h"
+#include <cstdlib>
 #include "mpcx_qp_stage.h"
 
 namespace mpcx {
@@ -131,7 +132,9 @@ template <int LQ, int SPL, bool JERK>
 void launch_qp_group(const QpArgs &a, hipStream_t st, int n_cu) {
     const int per_wave = 64 / LQ;
     const int need = (a.B + per_wave - 1) / per_wave;
-    const int resident = n_cu * 4;                      // one wavefront per SIMD
+    // one wavefront per SIMD; MPCX_QP_GRID_DIV=d (dev aid: several shards in flight on separate streams, each on 1/d of the chip)
+    static const int grid_div = [] { const char *e = getenv("MPCX_QP_GRID_DIV"); const int d = e ? atoi(e) : 1; return d >= 1 && d <= 16 ? d : 1; }();
+    const int resident = n_cu * 4 / grid_div;
     const int grid = need < resident ? need : resident;
     if (a.has_tune) hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, true, JERK>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, false, JERK>), dim3(grid), dim3(64), 0, st, a);

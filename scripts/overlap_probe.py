@@ -10,7 +10,7 @@ from mpc_for_av_at_intersection_amd.batch import stock_routes, synthetic_batch
 from mpc_for_av_at_intersection_amd.sharding import shard_instances
 
 B, K, W = 4096, 20, 3
-for S in (1, 2, 3, 4, 8):
+for S in [int(v) for v in os.environ.get('SHARDS', '1,2,4').split(',')]:
     streams = [torch.cuda.Stream() for _ in range(S)]
     ctxs = [Context(0, stream=s) for s in streams]
     with torch.cuda.stream(streams[0]):
