@@ -111,6 +111,15 @@ class MotionPrimitiveSearch:
                 best = d
         return best
 
+    def _reference_h(self, nodes: np.ndarray) -> np.ndarray:
+        """`distance_to_goal` of the 'modified' variant for an array of nodes with the reference's bits (what plan_many_device checks
+        the device's values against): the squares through Python's `**`, the rest is IEEE arithmetic numpy evaluates identically"""
+        gx, gy, gth = self._goal_point
+        ex, ey = nodes[:, 0] - gx, nodes[:, 1] - gy
+        sq = np.array([v ** 2 for v in ex.tolist()]) + np.array([v ** 2 for v in ey.tolist()])
+        ad = np.abs(nodes[:, 2] - gth)
+        return np.sqrt(sq) + 2.7 * np.minimum(ad, ad - self._allowed_goal_theta_difference / 2)
+
     def distance_to_goal(self, node: NodeType) -> float:
         x, y, theta = node
         if self.variant == 'base':                     # motion_primitive_search.py:71-75
@@ -373,11 +382,7 @@ def plan_many_device(searches: List['MotionPrimitiveSearch'], max_expansions: in
             if s.variant != 'base' and len(pl):
                 # motion_primitive_search_modified.py:80-89 with Python-float squares (`**` = libm pow); everything else is IEEE arithmetic that
                 # numpy evaluates identically, so only the squares are taken element by element
-                gx, gy, gth = s._goal_point
-                ex, ey = pl[:, 0] - gx, pl[:, 1] - gy
-                sq = np.array([v ** 2 for v in ex.tolist()]) + np.array([v ** 2 for v in ey.tolist()])
-                ad = np.abs(pl[:, 2] - gth)
-                ref = np.sqrt(sq) + 2.7 * np.minimum(ad, ad - s._allowed_goal_theta_difference / 2)
+                ref = s._reference_h(pl[:, :3])
                 for r in np.nonzero(ref != pl[:, 3])[0]:
                     overrides[(float(pl[r, 0]), float(pl[r, 1]), float(pl[r, 2]))] = float(ref[r])
                     bad += 1

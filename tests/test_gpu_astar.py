@@ -103,3 +103,43 @@ def test_1024_concurrent_searches_beat_the_host_queues():
           % (1e3 * t_dev, info['launches'], info['overrides'], 1e3 * info['t_closure'], 1e3 * info['t_device'], 1e3 * info['t_check'], len(cases), 1e3 * t_host,
              1e3 * t_host * 1024 / len(cases)))
     assert t_dev < t_host * 1024 / len(cases)
+
+
+def test_heuristic_override_round_trip():
+    """The override mechanism (host finds heuristic values that differ from the reference's bits -> override table -> the searches concerned
+    run again) forced: the 'reference' heuristic is bent by a node-dependent amount, on the host check and in the host search alike; the
+    device search must then reproduce the HOST search under the bent heuristic, expansion for expansion."""
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive_search import plan_many_device
+    cases = [c for c in _golden_cases() if c[0] == 'modified'][:4]
+    dev, host = _make(cases), _make(cases)
+
+    def bend(x, y):              # a few % of the nodes, by much more than an ulp so that the pop order really changes
+        return np.where(np.floor(np.abs(x * 3.0 + y * 5.0)) % 7 == 0, 0.05, 0.0)
+    for s in dev + host:
+        ref_h, d2g = s._reference_h, s.distance_to_goal
+        s._reference_h = (lambda nodes, f=ref_h: f(nodes) + bend(nodes[:, 0], nodes[:, 1]))
+        s.distance_to_goal = (lambda node, f=d2g: float(f(node) + bend(np.float64(node[0]), np.float64(node[1]))))
+    results, info = plan_many_device(dev, debug=True)
+    assert info['overrides'] > 0 and max(info['rounds']) >= 2
+    changed = 0
+    for sd, sh, c, (cost, path, traj) in zip(dev, host, cases, results):
+        hc, hp, _ = sh.run(debug=True)
+        assert cost == hc and path == hp
+        dd, hd = sd.debug_data, sh.debug_data
+        assert [d.node for d in dd] == [d.node for d in hd] and [d.g for d in dd] == [d.g for d in hd]
+        changed += len(hd) != len(H.gold('astar_runs.npz')[c[1] + 'dbg_g'])
+    assert changed > 0           # the bent heuristic did change the searches, i.e. the overrides mattered
+    print('override round trip: %d overrides, rounds %s' % (info['overrides'], info['rounds']))
+
+
+def test_heading_outside_the_table_is_added_and_the_search_rerun():
+    """A heading table too shallow for the search (closure depth 3): the kernel reports the missing heading, the host adds its closure and
+    runs the search again -- until the golden run comes out."""
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive_search import plan_many_device
+    runs = H.gold('astar_runs.npz')
+    cases = [c for c in _golden_cases() if c[1] in ('mod_bic_1_2/', 'mod_bic_2_1/')]
+    searches = _make(cases)
+    results, info = plan_many_device(searches, closure_depth=3, max_rounds=40, debug=True)
+    assert max(info['rounds']) >= 2
+    for s, c, (cost, path, traj) in zip(searches, cases, results):
+        _check(s, runs, c[1], cost, path, traj)
