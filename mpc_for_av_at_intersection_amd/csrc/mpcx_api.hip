@@ -74,6 +74,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
+    if (ctx->bins) (void)hipFree(ctx->bins);
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     (void)mpcx_comm_destroy(ctx);

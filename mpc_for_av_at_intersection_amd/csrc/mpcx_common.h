@@ -22,8 +22,19 @@ struct mpcx_ctx {
     const int32_t *order_now, *order_prev;   // optional pair: entries that differ mark a discontinuous change of the reference
     int32_t *prev_cut;          // scratch of mpcx_closed_loop_run: cut lengths of the previous step
     size_t prev_cut_cap;
-    int32_t *order;             // scratch: work-queue order built from the hint, and its two counters behind it
+    int32_t *order;             // scratch: work-queue order built from the hint | per-block key histograms | list of given-up problems | 2 counters
     size_t order_cap;
+    bool order_ready = false;   // mpcx_closed_loop_run: the order of this step's first solve is in `order` already and the ticket is zero
+    // closed loop: the counting sort of the work queue rides in the kernels of the step instead of two launches and two fills of its own.
+    // The conflict search files every agent under its queue key (bins[key]++ -> slot), the window selection turns (key, slot) into the
+    // agent's place in `order`, the plant kernel zeroes the bins and the ticket for the next step.
+    int32_t *bins = nullptr;    // [MPCX_ORDER_COPIES][MPCX_ORDER_BINS] counters (agent p counts in copy p % COPIES: 32 k atomics on 64 words are slow) | [P] (key << 24 | slot)
+    size_t bins_cap = 0;
+    bool bins_clean = false;    // host's knowledge: the counters and the ticket are zero (the last closed-loop step ran through and nothing has drawn tickets since)
+    const int32_t *bin_hint = nullptr;    // set around the conflict search: iteration counts of the previous step (queue key)
+    bool bin_scatter = false;             // set around the window selection: write `order`
+    bool bin_reset = false;               // set around the plant step: zero bins and ticket
+    int32_t *inter_prev_save = nullptr;   // mpcx_closed_loop_run: where the conflict search leaves the cut lengths it read (the queue order's `moved` test)
     hipStream_t side = nullptr; // side stream of mpcx_mpc_prepare_batch: the warm-start rollout runs beside the window selection (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool rollout_forked = false; // mpcx_closed_loop_run has the rollout of this step in flight on the side stream (mpcx_rollout_fork)
@@ -51,7 +62,22 @@ int32_t mpcx_check_launch(mpcx_ctx *ctx, const char *what);
 int32_t mpcx_ensure_pred(mpcx_ctx *ctx, size_t need_doubles);   // prediction scratch (mpcx_interaction.hip)
 int32_t mpcx_rollout_fork(mpcx_ctx *ctx, int32_t B, const double *state, const double *u_warm, double *xbar);   // mpcx_prepare.hip
 int32_t mpcx_ensure_ticket(mpcx_ctx *ctx);                      // work-queue word (mpcx_qp.hip)
+// Work-queue key: expected length of a solve.  hint = the previous step's iteration count; a problem whose path cut moved since
+// the previous step starts far from its warm start and is counted as MPCX_JUMP_BONUS iterations (mpcx_qp.hip has the measurements).
+#ifndef MPCX_JUMP_BONUS
+#define MPCX_JUMP_BONUS 11
+#endif
+#define MPCX_ORDER_BINS 64
+#define MPCX_ORDER_COPIES 16
+namespace mpcx {
+__device__ __forceinline__ int order_key_of(int hint, bool moved) {
+    int k = hint < 0 ? 0 : hint;
+    if (moved) k += MPCX_JUMP_BONUS;
+    return k < MPCX_ORDER_BINS ? k : MPCX_ORDER_BINS - 1;
+}
+}
 int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B);             // work-queue order scratch (mpcx_qp.hip)
+int32_t mpcx_qp_build_order(mpcx_ctx *ctx, int32_t B, hipStream_t st);   // counting sort of the work queue on stream st; also zeroes the ticket (mpcx_qp.hip)
 
 // fraction of the step to the boundary the interior-point iteration takes (both solvers must agree, and the tests' CPU checker
 // uses the same value).  0.995 in round 1; 0.999 saves 0.8 of 6.1 iterations on the closed-loop workload (numpy replica of the iteration over

@@ -60,6 +60,9 @@ struct InterArgs {
     double *hit_xy;
     int32_t *cut_len;
     int max_rem, fcap;    // capacity of this launch: path points ahead of an agent, resampled ego poses (dynamic LDS)
+    int32_t *prev_save;   // optional: the previous cut length as read (cut_len may alias prev_cut and is overwritten)
+    const int32_t *bin_hint;   // optional (closed loop): file the agent under its work-queue key: bin_cnt[p % COPIES][key]++ -> slot, keyslot[p] = key << 24 | slot
+    int32_t *bin_cnt, *keyslot;
 };
 
 __device__ __forceinline__ double dist2d(double ax, double ay, double bx, double by) {
@@ -270,8 +273,17 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     // ---- mpc_intersection.py:103-105: advance traj_agent_idx unless the previous tmp_trajectory collapsed onto it
     int tidx = a.traj_idx[p];
     bool advance = true;
-    if (a.prev_cut && a.prev_cut[p] > 0) {
-        const int last = a.prev_cut[p] - 1;
+    const int pcut = a.prev_cut ? a.prev_cut[p] : 0;
+    if (a.prev_save && lane == 0) a.prev_save[p] = pcut;
+    // lane 0, next to every store of cut_len: the agent's place in the QP work queue of this step
+    auto file_key = [&](int cl) {
+        if (a.bin_cnt) {
+            const int k = order_key_of(a.bin_hint ? a.bin_hint[p] : 0, cl != pcut);
+            a.keyslot[p] = (k << 24) | atomicAdd(&a.bin_cnt[(p % MPCX_ORDER_COPIES) * MPCX_ORDER_BINS + k], 1);
+        }
+    };
+    if (pcut > 0) {
+        const int last = pcut - 1;
         advance = (path[3 * tidx] != path[3 * last]) || (path[3 * tidx + 1] != path[3 * last + 1]) ||
                   (path[3 * tidx + 2] != path[3 * last + 2]);
     }
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     const int n_old = len - t_old;
     const int nobs = a.obs_cnt[p] - ((a.obs_skip && a.obs_skip[p] >= 0) ? 1 : 0);
     if (n_old > MAXREM || nobs > MPCX_MAX_OBS) {
-        if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; file_key(len); a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
     }
     // ONE pass over the remaining path: distances to the ego (per-lane three smallest, ties by lower index) for
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
         }
     }
     if (tidx < 0) {
-        if (lane == 0) { a.hit_idx[p] = -3; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        if (lane == 0) { a.hit_idx[p] = -3; a.cut_len[p] = len; file_key(len); a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
     }
     if (lane == 0) a.traj_idx[p] = tidx;
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     const int n = len - tidx;
     const int shift = tidx - t_old;                   // s_cum[shift + i] = step length into point i of the new trajectory
     if (nobs <= 0) {    // collision_avoidance.py:69-70
-        if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; file_key(len); a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
     }
     __syncthreads();
@@ -465,7 +477,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
         na = resample(false, unsure);
     }
     if (na > MAXF) {
-        if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; file_key(len); a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
     }
     __syncthreads();
@@ -488,7 +500,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, s_queue, lane, hx, hy);
     ISTAMP(5);      // conflict search (+ path scan on a hit)
     if (first < 0) {
-        if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+        if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; file_key(len); a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
         return;
     }
     // ---- collision_avoidance.py:107-119 on trajectory_full, then mpc_intersection.py:130-134
@@ -503,7 +515,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     cut = wave_min_i(cut);
     int cl = len;
     if (cut != 0x7fffffff) { cl = cut - ip.cutoff_margin; cl = cl > tidx + 1 ? cl : tidx + 1; }
-    if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = hx; a.hit_xy[2 * p + 1] = hy; a.cut_len[p] = cl; }
+    if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = hx; a.hit_xy[2 * p + 1] = hy; a.cut_len[p] = cl; file_key(cl); }
     ISTAMP(6);      // cut index
 }
 
@@ -602,7 +614,8 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
     const int fcap = max_rem / 4 - mpcx::QCAP * 2 / 32;
     const size_t lds = (size_t)max_rem * sizeof(double) + (size_t)fcap * sizeof(int);
     mpcx::InterArgs ia{*ip, P, state, path_xyyaw, path_cs, path_off, path_len, prev_cut_len, ctx->pred,
-                       obs_off, obs_cnt, obs_skip, traj_idx, hit_idx, hit_xy, cut_len, max_rem, fcap};
+                       obs_off, obs_cnt, obs_skip, traj_idx, hit_idx, hit_xy, cut_len, max_rem, fcap, ctx->inter_prev_save,
+                       ctx->bin_hint, ctx->bin_hint ? ctx->bins : nullptr, ctx->bin_hint ? ctx->bins + MPCX_ORDER_COPIES * MPCX_ORDER_BINS : nullptr};
     hipLaunchKernelGGL(mpcx::interaction_kernel, dim3(P), dim3(64), lds, ctx->stream, ia);
     return mpcx_check_launch(ctx, "interaction kernels");
 }

@@ -30,9 +30,7 @@ __global__ __launch_bounds__(256) void pack_pool_kernel(PackArgs a) {
 
 static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, const mpcx_closed_loop *c) {
     const int P = c->P;
-    // cut lengths of the previous step: the queue of the QP kernel puts the agents whose cut moved at the front
-    if (hipMemcpyAsync(ctx->prev_cut, c->cut_len, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
-        return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipMemcpyAsync failed");
+    ctx->bins_clean = false;        // until the plant kernel of this step is enqueued
     int32_t rc, pool_rows = P;
     // the warm-start rollout of this step needs only the states and the previous solution: it runs on the side stream BESIDE the pool pack,
     // the prediction and the conflict search (a chain of T dependent sincos / tan per agent, 35-45 us) and is joined by the window selection
@@ -50,29 +48,42 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
         mpcx::PackArgs pa{P, c->state, c->applied, c->obs6};
         hipLaunchKernelGGL(mpcx::pack_pool_kernel, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, pa);
     }
+    // the conflict search leaves the cut lengths of the previous step in ctx->prev_cut (the queue of the QP kernel puts the agents whose
+    // cut moved at the front) and files every agent under its work-queue key (previous iteration count + "the cut moved"): hard problems first.  The window
+    // selection then writes the queue order and the plant kernel resets bins and ticket, so the counting sort costs no launch of its own.
+    const bool binned = P < (1 << 24);
+    ctx->inter_prev_save = ctx->prev_cut;
+    ctx->bin_hint = binned ? c->iters : nullptr;
     rc = mpcx_interaction_batch(ctx, ip, P, c->state, c->path_xyyaw, c->path_cs, c->path_off, c->path_len,
                                 c->cut_len /* previous step's cut; read before it is rewritten */, pool_rows, c->obs6,
                                 c->obs_off, c->obs_cnt, c->obs_skip, c->traj_idx, c->hit_idx, c->hit_xy, c->cut_len);
+    ctx->inter_prev_save = nullptr;
+    ctx->bin_hint = nullptr;
     if (rc != MPCX_OK) return rc;
     // lib/mpc.py:226-237: MAX_ITER passes of (reference window, rollout, QP); from the second pass on the window is spaced by the
     // previous pass's speeds (row 2 of its x) and the rollout uses its inputs.  (Where a pass fails the reference crashes in the next
     // one -- zip over None; here the next pass starts from the untouched warm start, as after a failed step.)
     const int Wd = ctx->mpc.T + 1;
     for (int pass = 0; pass < ctx->lin_passes; pass++) {
+        ctx->bin_scatter = binned && pass == 0;
         rc = mpcx_mpc_prepare_batch_ov(ctx, P, c->state, c->u_sol, c->path_xyyaw, c->path_v, c->path_off, c->cut_len, c->dl,
                                        c->target_ind, pass ? c->x_sol + 2 * Wd : nullptr, 4 * (int64_t)Wd, c->xref, c->reaches_end, c->xbar);
         if (rc != MPCX_OK) return rc;
-        // hard problems first: the previous step's iteration counts (zero-initialised by the caller) order the work queue
+        // (further linearisation passes build their order in line, from the iteration counts of the pass before)
         const int32_t *hint_before = ctx->order_hint, *now_before = ctx->order_now, *prev_before = ctx->order_prev;
         ctx->order_hint = c->iters; ctx->order_now = c->cut_len; ctx->order_prev = ctx->prev_cut;
+        ctx->order_ready = binned && pass == 0;
         rc = mpcx_qp_solve_batch(ctx, P, c->state, c->xref, c->xbar, c->reaches_end, c->u_sol, c->x_sol, c->u_sol,
                                  c->status, c->iters, c->kkt);
         ctx->order_hint = hint_before; ctx->order_now = now_before; ctx->order_prev = prev_before;
+        ctx->order_ready = false;
         if (rc != MPCX_OK) return rc;
     }
     ctx->stats_iters = c->iters;
+    ctx->bin_reset = binned;
     rc = mpcx_plant_step_batch(ctx, P, c->state, c->u_sol, c->status, c->applied);
     ctx->stats_iters = nullptr;
+    if (rc == MPCX_OK) ctx->bins_clean = binned;
     return rc;
 }
 
@@ -116,6 +127,23 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     }
     rc = mpcx_ensure_order(ctx, (size_t)c->P);
     if (rc != MPCX_OK) return rc;
+    {       // queue bins: counters + (key, slot) per agent.  The plant kernel leaves counters and ticket zeroed step by step; they are
+            // filled here only when the host cannot know that (first run, a step that failed half way, a solve outside the loop since)
+        const size_t need = (size_t)MPCX_ORDER_COPIES * MPCX_ORDER_BINS + (size_t)c->P;
+        if (need > ctx->bins_cap) {
+            if (ctx->bins) (void)hipFree(ctx->bins);
+            ctx->bins = nullptr; ctx->bins_cap = 0; ctx->bins_clean = false;
+            if (hipMalloc((void **)&ctx->bins, need * sizeof(int32_t)) != hipSuccess)
+                return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: cannot allocate the queue bins of %d agents", c->P);
+            ctx->bins_cap = need;
+        }
+        if (!ctx->bins_clean) {
+            if (hipMemsetAsync(ctx->bins, 0, (size_t)MPCX_ORDER_COPIES * MPCX_ORDER_BINS * sizeof(int32_t), ctx->stream) != hipSuccess ||
+                hipMemsetAsync(ctx->ticket, 0, sizeof(int32_t), ctx->stream) != hipSuccess)
+                return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipMemsetAsync failed");
+            ctx->bins_clean = true;
+        }
+    }
     if ((size_t)c->P > ctx->prev_cut_cap) {
         if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
         ctx->prev_cut = nullptr; ctx->prev_cut_cap = 0;
@@ -137,7 +165,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     if (ctx->prof_qp)       // the event pairs of mpcx_profile_qp cannot be recorded inside a replayed graph: say so instead of reporting 0 launches
         return mpcx_fail(ctx, MPCX_E_INVALID, "closed_loop_run: mpcx_profile_qp is on; the QP launches of a replayed graph are not bracketed by events -- run without graph or switch the hook off");
     unsigned char key[sizeof ctx->loop_key];
-    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 8 * sizeof(void *) <= sizeof key,
+    static_assert(sizeof(mpcx_closed_loop) + sizeof(mpcx_interaction_params) + sizeof(mpcx_mpc_params) + 9 * sizeof(void *) <= sizeof key,
                   "loop_key too small");
     memset(key, 0, sizeof key);
     size_t o = 0;
@@ -148,6 +176,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     memcpy(key + o, &ctx->tune, sizeof ctx->tune); o += sizeof ctx->tune;
     memcpy(key + o, &ctx->order, sizeof ctx->order); o += sizeof ctx->order;
     memcpy(key + o, &ctx->prev_cut, sizeof ctx->prev_cut); o += sizeof ctx->prev_cut;
+    memcpy(key + o, &ctx->bins, sizeof ctx->bins); o += sizeof ctx->bins;
     memcpy(key + o, &ctx->qp_solver, sizeof ctx->qp_solver); o += sizeof ctx->qp_solver;      // the captured launch is the solver chosen at capture time
     memcpy(key + o, &ctx->lin_passes, sizeof ctx->lin_passes); o += sizeof ctx->lin_passes;
     memcpy(key + o, &ctx->stats, sizeof ctx->stats);

@@ -22,11 +22,32 @@ struct RefArgs {
     uint8_t *re;
     const double *ov;       // speeds of the previous linearisation pass (mpc.py:226-237, MAX_ITER > 1): row b at ov + b * ov_stride, or nullptr
     long ov_stride;
+    const int32_t *bin_cnt, *keyslot;   // closed loop: the conflict search filed agent b as (key, slot) = keyslot[b]; its place in the QP work queue
+    int32_t *order;                     // (keys descending) = number of agents with a larger key + slot.  nullptr: no queue order is built
 };
 
 __device__ __forceinline__ void ref_window_block(const RefArgs &a, int b) {
     const int lane = threadIdx.x & 63;
     const int T = a.p.T, W = T + 1;
+    if (a.order) {
+        // lane k holds bin k.  Agents with a larger key come first (suffix sums over the bins by shuffles), then the agents of the same key
+        // that counted in a lower copy of the bins, then the slot the conflict search drew
+        static_assert(MPCX_ORDER_BINS == 64, "one bin per lane");
+        const int mine = b % MPCX_ORDER_COPIES;
+        int c = 0, lower = 0;
+#pragma unroll
+        for (int q = 0; q < MPCX_ORDER_COPIES; q++) {
+            const int v = a.bin_cnt[q * MPCX_ORDER_BINS + lane];
+            c += v;
+            lower += q < mine ? v : 0;
+        }
+        int sfx = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_down(sfx, d); sfx += lane + d < 64 ? o : 0; }
+        const int ks = a.keyslot[b];
+        const int first = __shfl(sfx - c + lower, ks >> 24);
+        if (lane == 0) a.order[first + (ks & 0xFFFFFF)] = b;
+    }
     const double *path = a.path + 3 * (size_t)a.path_off[b];
     const double *pv = a.path_v ? a.path_v + (size_t)a.path_off[b] : nullptr;   // mpc_with_speed.py:103-104
     const int n = a.path_len[b];
@@ -128,10 +149,15 @@ struct PlantArgs {
     const int32_t *iters;         // closed loop only: the solver's iteration counts ...
     unsigned long long *stats;    // ... and the run statistics they are added to: agent-steps, iterations, failed solves, max iterations
     int has_stats;
+    int32_t *zero_bins, *zero_ticket;   // closed loop: the queue bins and the ticket are zeroed for the next step (nullptr otherwise)
 };
 
 // MPC.step's tail (mpc.py:294-297) + Simulation.step
 __global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
+    if (a.zero_bins && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < MPCX_ORDER_COPIES * MPCX_ORDER_BINS; i += blockDim.x) a.zero_bins[i] = 0;
+        if (threadIdx.x == 0) *a.zero_ticket = 0;
+    }
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (a.has_stats) {          // run statistics (mpcx_closed_loop_stats)
         const bool in = b < a.B;
@@ -186,7 +212,10 @@ extern "C" int32_t mpcx_mpc_prepare_batch_ov(mpcx_ctx *ctx, int32_t B, const dou
     if (B == 0) return MPCX_OK;
     if (ov && ov_stride < (int64_t)ctx->mpc.T + 1)
         return mpcx_fail(ctx, MPCX_E_INVALID, "mpc_prepare_batch_ov: ov_stride %lld is smaller than T + 1", (long long)ov_stride);
-    mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end, ov, (long)ov_stride};
+    const bool scatter = ctx->bin_scatter;
+    ctx->bin_scatter = false;
+    mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end, ov, (long)ov_stride,
+                     scatter ? ctx->bins : nullptr, scatter ? ctx->bins + MPCX_ORDER_COPIES * MPCX_ORDER_BINS : nullptr, scatter ? ctx->order : nullptr};
     // the rollout may already be in flight: mpcx_closed_loop_run forks it at the start of the step, beside the conflict search
     const bool forked = ctx->rollout_forked;
     ctx->rollout_forked = false;
@@ -221,7 +250,10 @@ extern "C" int32_t mpcx_plant_step_batch(mpcx_ctx *ctx, int32_t B, double *state
         return mpcx_fail(ctx, MPCX_E_INVALID, "plant_step_batch: %d tuning rows are set but the batch has %d agents", ctx->tune_rows, B);
     // inside mpcx_closed_loop_run the step also feeds the run statistics (ctx->stats_iters names the step's iteration counts)
     const bool st = ctx->stats && ctx->stats_iters && status;
-    mpcx::PlantArgs pa{ctx->mpc, B, state, u, status, applied, ctx->tune, ctx->stats_iters, ctx->stats, st ? 1 : 0};
+    const bool rz = ctx->bin_reset && ctx->bins && ctx->ticket;
+    ctx->bin_reset = false;
+    mpcx::PlantArgs pa{ctx->mpc, B, state, u, status, applied, ctx->tune, ctx->stats_iters, ctx->stats, st ? 1 : 0,
+                       rz ? ctx->bins : nullptr, rz ? ctx->ticket : nullptr};
     hipLaunchKernelGGL(mpcx::plant_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, pa);
     return mpcx_check_launch(ctx, "plant_kernel");
 }

@@ -699,46 +699,61 @@ namespace mpcx {
 // (scripts/predict_probe.py: 100 % of them, 15 % of the moved ones); a launch lasts as long as its last problem, so those must
 // start in round 0, ahead of the known 6-10-iteration ones: bonus 11 (6 until the trial pass: 0.864 -> 0.82 ms per launch;
 // 3 / 8 / 9 / 10 / 12 / 14 / 20: 0.868 / 0.844 / 0.833 / 0.818 / 0.822 / 0.830 / 0.840).
-#ifndef MPCX_JUMP_BONUS
-#define MPCX_JUMP_BONUS 11
-#endif
-constexpr int ORDER_BINS = 64, JUMP_BONUS = MPCX_JUMP_BONUS;
+constexpr int ORDER_BINS = MPCX_ORDER_BINS;
 __device__ __forceinline__ int order_key(int i, const int32_t *hint, const int32_t *now, const int32_t *prev) {
-    int k = hint ? hint[i] : 0;
-    k = k < 0 ? 0 : k;
-    if (now && now[i] != prev[i]) k += JUMP_BONUS;
-    return k < ORDER_BINS ? k : ORDER_BINS - 1;
+    return order_key_of(hint ? hint[i] : 0, now && now[i] != prev[i]);
 }
-__global__ __launch_bounds__(256) void qp_order_hist_kernel(int B, const int32_t *hint, const int32_t *now, const int32_t *prev, int32_t *hist) {
+// Counting sort in two launches without zero-fills or global atomics: every block leaves its own key histogram (block_hist[b][64]);
+// the scatter blocks add up the histograms in front of them.  Block 0 of the scatter also resets the work-queue ticket.
+constexpr int ORDER_BLOCK = 256;
+__global__ __launch_bounds__(ORDER_BLOCK) void qp_order_hist_kernel(int B, const int32_t *hint, const int32_t *now, const int32_t *prev, int32_t *block_hist) {
     __shared__ int32_t h[ORDER_BINS];
     if (threadIdx.x < ORDER_BINS) h[threadIdx.x] = 0;
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) atomicAdd(&h[order_key(i, hint, now, prev)], 1);
     __syncthreads();
-    if (threadIdx.x < ORDER_BINS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x < ORDER_BINS) block_hist[blockIdx.x * ORDER_BINS + threadIdx.x] = h[threadIdx.x];
 }
-__global__ __launch_bounds__(256) void qp_order_scatter_kernel(int B, const int32_t *hint, const int32_t *now, const int32_t *prev,
-                                                               const int32_t *hist, int32_t *cursor, int32_t *order) {
-    __shared__ int32_t start[ORDER_BINS], h[ORDER_BINS], base[ORDER_BINS];
-    if (threadIdx.x < ORDER_BINS) h[threadIdx.x] = 0;
+__global__ __launch_bounds__(ORDER_BLOCK) void qp_order_scatter_kernel(int B, const int32_t *hint, const int32_t *now, const int32_t *prev,
+                                                                       const int32_t *block_hist, int32_t *order, int32_t *ticket) {
+    __shared__ int32_t total[ORDER_BINS], base[ORDER_BINS], h[ORDER_BINS], part_all[ORDER_BLOCK], part_before[ORDER_BLOCK];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;
+    {       // thread (part, bin) adds up every (ORDER_BLOCK / ORDER_BINS)-th block histogram: the loads of a thread are independent
+        const int k = threadIdx.x % ORDER_BINS;
+        int all = 0, before = 0;
+        for (int b = threadIdx.x / ORDER_BINS; b < (int)gridDim.x; b += ORDER_BLOCK / ORDER_BINS) {
+            const int c = block_hist[b * ORDER_BINS + k];
+            all += c;
+            before += b < (int)blockIdx.x ? c : 0;
+        }
+        part_all[threadIdx.x] = all; part_before[threadIdx.x] = before;
+    }
+    __syncthreads();
+    if (threadIdx.x < ORDER_BINS) {
+        int all = 0, before = 0;
+        for (int q = 0; q < ORDER_BLOCK / ORDER_BINS; q++) { all += part_all[q * ORDER_BINS + threadIdx.x]; before += part_before[q * ORDER_BINS + threadIdx.x]; }
+        total[threadIdx.x] = all; base[threadIdx.x] = before; h[threadIdx.x] = 0;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {               // bins in descending key order: start of bin k = number of problems with a larger key
         int acc = 0;
-        for (int k = ORDER_BINS - 1; k >= 0; k--) { start[k] = acc; acc += hist[k]; }
+        for (int k = ORDER_BINS - 1; k >= 0; k--) { const int t = total[k]; base[k] += acc; acc += t; }
     }
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int k = 0, r = 0;
-    if (i < B) { k = order_key(i, hint, now, prev); r = atomicAdd(&h[k], 1); }      // rank inside the block (LDS atomic)
-    __syncthreads();
-    if (threadIdx.x < ORDER_BINS) base[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0;   // one global atomic per block and bin
-    __syncthreads();
-    if (i < B) order[start[k] + base[k] + r] = i;
+    if (i < B) {
+        const int k = order_key(i, hint, now, prev);
+        order[base[k] + atomicAdd(&h[k], 1)] = i;       // rank inside the block (LDS atomic)
+    }
 }
 }  // namespace mpcx
 
+static inline size_t order_blocks(size_t B) { return (B + mpcx::ORDER_BLOCK - 1) / mpcx::ORDER_BLOCK; }
+static inline int32_t *order_fail_list(mpcx_ctx *ctx, size_t B) { return ctx->order + B + order_blocks(B) * mpcx::ORDER_BINS; }
+
 int32_t mpcx_ensure_order(mpcx_ctx *ctx, size_t B) {
-    const size_t need = 2 * B + 2 * mpcx::ORDER_BINS + 2;       // order | bins | list of given-up problems | its counter and ticket
+    const size_t need = 2 * B + order_blocks(B) * mpcx::ORDER_BINS + 2;       // order | block histograms | list of given-up problems | its counter and ticket
     if (need <= ctx->order_cap) return MPCX_OK;
     if (ctx->order) (void)hipFree(ctx->order);
     ctx->order = nullptr; ctx->order_cap = 0;
@@ -754,6 +769,20 @@ int32_t mpcx_ensure_ticket(mpcx_ctx *ctx) {
     return MPCX_OK;
 }
 
+// both solvers draw their problems from a queue, longest expected job first: order (ctx->order[0..B)) from ctx->order_hint / order_now / order_prev
+int32_t mpcx_qp_build_order(mpcx_ctx *ctx, int32_t B, hipStream_t st) {
+    int32_t rc = mpcx_ensure_order(ctx, (size_t)B);
+    if (rc != MPCX_OK) return rc;
+    rc = mpcx_ensure_ticket(ctx);
+    if (rc != MPCX_OK) return rc;
+    int32_t *block_hist = ctx->order + B;
+    const int nb = (int)order_blocks((size_t)B);
+    hipLaunchKernelGGL(mpcx::qp_order_hist_kernel, dim3(nb), dim3(mpcx::ORDER_BLOCK), 0, st, B, ctx->order_hint, ctx->order_now, ctx->order_prev, block_hist);
+    hipLaunchKernelGGL(mpcx::qp_order_scatter_kernel, dim3(nb), dim3(mpcx::ORDER_BLOCK), 0, st, B, ctx->order_hint, ctx->order_now, ctx->order_prev,
+                       block_hist, ctx->order, ctx->ticket);
+    return MPCX_OK;
+}
+
 extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x0, const double *xref,
                                        const double *xbar, const uint8_t *reaches_end, const double *u_warm,
                                        double *x_out, double *u_out, int32_t *status, int32_t *iters, double *kkt) {
@@ -764,8 +793,7 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: null pointer or negative batch");
     if (B == 0) return MPCX_OK;
     { int32_t rc = mpcx_ensure_ticket(ctx); if (rc != MPCX_OK) return rc; }
-    if (hipMemsetAsync(ctx->ticket, 0, sizeof(int32_t), ctx->stream) != hipSuccess)
-        return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipMemsetAsync failed");
+    if (!ctx->order_ready) ctx->bins_clean = false;      // this solve draws tickets outside the closed loop's bookkeeping
     // persistent wavefronts: one per SIMD slot the kernel can occupy (1 wave/SIMD, 4 SIMDs/CU), never more than B
     const int grid = B < ctx->n_cu * 4 ? B : ctx->n_cu * 4;
     if (ctx->tune && ctx->tune_rows != B)
@@ -778,18 +806,15 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         return mpcx_fail(ctx, MPCX_E_INVALID, "qp_solve_batch: the condensed solver has no five-state (lib/mpc_jerk.py) variant; use solver 0 or 2");
     const bool use_stage = solver == 2 || ctx->mpc.model == MPCX_MODEL_JERK5 || (solver == 0 && (T > 20 || B >= MPCX_STAGE_MIN_BATCH));
     const int32_t *order = nullptr;
-    if (ctx->order_hint || ctx->order_now) {      // both solvers draw their problems from a queue: longest expected job first
-        int32_t rc = mpcx_ensure_order(ctx, (size_t)B);
-        if (rc != MPCX_OK) return rc;
-        int32_t *hist = ctx->order + B, *cursor = hist + mpcx::ORDER_BINS;
-        if (hipMemsetAsync(hist, 0, 2 * mpcx::ORDER_BINS * sizeof(int32_t), ctx->stream) != hipSuccess)
-            return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipMemsetAsync failed");
-        const int nb = (B + 255) / 256;
-        hipLaunchKernelGGL(mpcx::qp_order_hist_kernel, dim3(nb), dim3(256), 0, ctx->stream, B, ctx->order_hint, ctx->order_now, ctx->order_prev, hist);
-        hipLaunchKernelGGL(mpcx::qp_order_scatter_kernel, dim3(nb), dim3(256), 0, ctx->stream, B, ctx->order_hint, ctx->order_now, ctx->order_prev,
-                           hist, cursor, ctx->order);
+    if (ctx->order_ready) {                       // mpcx_closed_loop_run built it beside the window selection (and the scatter zeroed the ticket)
+        ctx->order_ready = false;
         order = ctx->order;
-    }
+    } else if (ctx->order_hint || ctx->order_now) {      // both solvers draw their problems from a queue: longest expected job first
+        int32_t rc = mpcx_qp_build_order(ctx, B, ctx->stream);
+        if (rc != MPCX_OK) return rc;
+        order = ctx->order;
+    } else if (hipMemsetAsync(ctx->ticket, 0, sizeof(int32_t), ctx->stream) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipMemsetAsync failed");
     mpcx::QpArgs a{ctx->mpc, B, ctx->ticket, u_warm != nullptr, x0, xref, xbar, u_warm, reaches_end, x_out, u_out, kkt, status, iters,
                    ctx->tune, ctx->tune != nullptr, order, order != nullptr, 0, nullptr, nullptr, nullptr, 0};
     if (!use_stage) {
@@ -799,8 +824,8 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         // leaves them untouched and lists them, a small stage-solver launch (a few microseconds when the list is empty) solves them.
         int32_t rc = mpcx_ensure_order(ctx, (size_t)B);
         if (rc != MPCX_OK) return rc;
-        // the list of given-up problems sits behind the order and its bins (B order entries | 2 x ORDER_BINS | B list entries | 2 counters)
-        a.defer_fail = 1; a.fail_list = ctx->order + B + 2 * mpcx::ORDER_BINS; a.fail_count = a.fail_list + B;
+        // the list of given-up problems sits behind the order and its block histograms (B order entries | histograms | B list entries | 2 counters)
+        a.defer_fail = 1; a.fail_list = order_fail_list(ctx, (size_t)B); a.fail_count = a.fail_list + B;
         if (hipMemsetAsync(a.fail_count, 0, 2 * sizeof(int32_t), ctx->stream) != hipSuccess)
             return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: hipMemsetAsync failed");
     }
