@@ -16,13 +16,40 @@
 
 namespace mpcx {
 
+#ifndef MPCX_EXP_CHUNKS
+#define MPCX_EXP_CHUNKS 1
+#endif
+constexpr int EXP_CHUNKS = MPCX_EXP_CHUNKS;
+
 __device__ __forceinline__ void expand_block(const ExpandArgs &a, unsigned block_in_segment) {
     __shared__ ExpandTables t;
     expand_stage(a, t);
-    expand_records(a, t, block_in_segment);
+    expand_records(a, t, block_in_segment);          // 256 consecutive records per block, per-lane loops
 }
 
+// small launches (a search's frontier), any model size
 __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) { expand_block(a, blockIdx.x); }
+
+// bulk launches: floor(256 / n_prim) nodes per block, the (record, obstacle) pairs of a wavefront worked off together
+// (expand_records_coop), tables in dynamic LDS at the model's sizes
+#ifndef MPCX_EXP_WAVES
+#define MPCX_EXP_WAVES 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MPCX_EXP_WAVES, 8))) void expand_coop_kernel(ExpandArgs a) {
+    extern __shared__ double s_dyn[];
+    ExpandCoop &co = *reinterpret_cast<ExpandCoop *>(s_dyn);
+    ExpandTablesView t = expand_view(a, s_dyn + sizeof(ExpandCoop) / sizeof(double));
+    for (int i = threadIdx.x; i < a.n_prim * 5; i += blockDim.x) co.tbox[i / 5][i % 5] = a.tbox[i];
+    expand_stage(a, t);                                   // ends with the block's barrier
+    // EXP_CHUNKS groups of floor(256 / n_prim) nodes per block: the staging above is paid once for all of them (the wavefronts of a block
+    // run their groups independently: nothing below is block-wide)
+    const int npb = expand_nodes_per_block(a.n_prim);
+    for (int j = 0; j < EXP_CHUNKS; j++) {
+        const unsigned g = blockIdx.x * EXP_CHUNKS + j;
+        if ((long long)g * npb >= a.n_nodes) break;
+        expand_records_coop(a, t, co, g);
+    }
+}
 
 // cos / sin of every node's heading, once per NODE: the records of a node (one per primitive) would otherwise each evaluate the
 // same double-precision sincos, ~150 of the ~1000 instructions of a record in a kernel that is bound by instruction issue
@@ -101,10 +128,25 @@ extern "C" mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_
             roff[(size_t)o + 1] = (int32_t)(rest.size() / 3);
         }
         m->n_rest = (int)(rest.size() / 3);
+        std::vector<double> tb((size_t)n_prim * 5);
+        for (int k = 0; k < n_prim; k++) {
+            double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY, r = 0.0;
+            for (int i = tmpl_off[k]; i < tmpl_off[k + 1]; i++) {
+                const double px = tmpl_xy[2 * i], py = tmpl_xy[2 * i + 1];
+                xlo = fmin(xlo, px); xhi = fmax(xhi, px); ylo = fmin(ylo, py); yhi = fmax(yhi, py);
+                r = fmax(r, fmax(fabs(px), fabs(py)));
+            }
+            if (tmpl_off[k + 1] <= tmpl_off[k]) { xlo = xhi = ylo = yhi = 0.0; }      // no points: the box is never used for a hit
+            tb[5 * k] = xlo; tb[5 * k + 1] = xhi; tb[5 * k + 2] = ylo; tb[5 * k + 3] = yhi; tb[5 * k + 4] = r;
+        }
+        m->d_tbox = to_device(tb.data(), tb.size());
+        m->div_magic = (65536 + n_prim - 1) / n_prim;
+        for (int x = 0; x < 256; x++)
+            if (((x * m->div_magic) >> 16) != x / n_prim) m->div_magic = 0;
         m->d_rest = to_device(rest.data(), rest.size());
         m->d_rest_off = to_device(roff.data(), roff.size());
     }
-    if (!m->d_tmpl_off || !m->d_hp_off || !m->d_tmpl_xy || !m->d_last_pose || !m->d_edge_cost || !m->d_hp || !m->d_aabb || !m->d_rest || !m->d_rest_off) {
+    if (!m->d_tmpl_off || !m->d_hp_off || !m->d_tmpl_xy || !m->d_last_pose || !m->d_edge_cost || !m->d_hp || !m->d_aabb || !m->d_rest || !m->d_rest_off || !m->d_tbox) {
         mpcx_fail(ctx, MPCX_E_LAUNCH, "search_model_create: device allocation failed");
         mpcx_search_model_destroy(m);
         return nullptr;
@@ -160,7 +202,7 @@ extern "C" void mpcx_search_model_destroy(mpcx_search_model *m) {
     if (!m) return;
     (void)hipFree(m->d_tmpl_off); (void)hipFree(m->d_hp_off); (void)hipFree(m->d_tmpl_xy);
     (void)hipFree(m->d_last_pose); (void)hipFree(m->d_edge_cost); (void)hipFree(m->d_hp); (void)hipFree(m->d_aabb);
-    (void)hipFree(m->d_rest); (void)hipFree(m->d_rest_off);
+    (void)hipFree(m->d_rest); (void)hipFree(m->d_rest_off); (void)hipFree(m->d_tbox);
     delete m;
 }
 
@@ -182,10 +224,19 @@ extern "C" int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, 
         hipLaunchKernelGGL(mpcx::node_cs_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, ctx->stream, n_nodes, nodes, ctx->cs);
         nodes_cs = ctx->cs;
     }
+    // bulk launches (>= 4096 nodes) take the cooperative records of mpcx_expand_core.h, small ones (a search's frontier) the per-lane loop
+    const bool coop = n_nodes >= 4096 && m->div_magic != 0;
     mpcx::ExpandArgs a{m->n_prim, m->n_obst, m->n_pts, m->n_rest, n_nodes, m->d_tmpl_off, m->d_rest_off,
-                       m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_rest, m->d_aabb, nodes, nodes_cs, nbr, cost, collide};
+                       m->d_tmpl_xy, m->d_last_pose, m->d_edge_cost, m->d_rest, m->d_aabb, nodes, nodes_cs, nbr, cost, collide,
+                       coop ? m->d_tbox : nullptr, m->div_magic};
     const long long total = (long long)n_nodes * m->n_prim;
-    const unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(mpcx::expand_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    const int npb = 256 / m->n_prim;
+    const unsigned blocks = coop ? (unsigned)(((long long)n_nodes + npb - 1) / npb) : (unsigned)((total + 255) / 256);
+    static_assert(sizeof(mpcx::ExpandCoop) % sizeof(double) == 0, "the tables follow the wavefront scratch in dynamic LDS");
+    if (coop) {
+        const size_t lds = sizeof(mpcx::ExpandCoop) + mpcx::expand_view_bytes(m->n_rest, m->n_pts, m->n_obst, m->n_prim);
+        hipLaunchKernelGGL(mpcx::expand_coop_kernel, dim3((blocks + mpcx::EXP_CHUNKS - 1) / mpcx::EXP_CHUNKS), dim3(256), lds, ctx->stream, a);
+    } else
+        hipLaunchKernelGGL(mpcx::expand_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
     return mpcx_check_launch(ctx, "expand_kernel");
 }

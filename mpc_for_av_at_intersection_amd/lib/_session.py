@@ -6,7 +6,7 @@ _ctx = None
 
 def context() -> Context:
     global _ctx
-    if _ctx is None:
+    if _ctx is None or not getattr(_ctx, '_ctx', None):      # none yet, or its owner closed it: the drop-in classes get a fresh one
         _ctx = Context(0)
     return _ctx
 

@@ -210,6 +210,13 @@ def test_expansion_one_million_nodes(ctx):
     onbr, ocol = orc.expand(om, nodes[idx], host_trig=False)
     assert np.array_equal(ocol, col[idx]) and np.abs(onbr - nbr[idx]).max() < 1e-12
     assert 0.05 < 1.0 - col.mean() < 0.9                                        # both outcomes occur
+    # the bulk kernel (>= 4096 nodes: the wavefront works its (record, obstacle) pairs off together, record boxes from the template's box)
+    # against the per-lane kernel of the small launches (exact point boxes): the same records, bit for bit
+    cost = out['cost'].cpu().numpy()
+    for lo in list(range(0, 160000, 4000)) + [n - 4000]:
+        part = ctx.expand(model, dev[lo:lo + 4000].contiguous())
+        assert np.array_equal(part['collide'].cpu().numpy(), col[lo:lo + 4000]) and np.array_equal(part['nbr'].cpu().numpy(), nbr[lo:lo + 4000])
+        assert np.array_equal(part['cost'].cpu().numpy(), cost[lo:lo + 4000])
     # throughput, for the record (not asserted)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
