@@ -104,7 +104,9 @@ extern "C" mpcx_search_model *mpcx_search_model_create(mpcx_ctx *ctx, int32_t n_
     m->d_edge_cost = to_device(edge_cost, n_prim);
     m->d_hp = to_device(hp, (size_t)n_rows * 3);
     {
-        std::vector<double> box((size_t)(n_obst ? n_obst : 1) * 4);
+        // padded to a multiple of four boxes with boxes no record reaches (the bulk kernel culls four at a time)
+        std::vector<double> box((size_t)((n_obst + 3) / 4 * 4 + 4) * 4, 0.0);
+        for (size_t o = (size_t)n_obst; o < box.size() / 4; o++) { box[4 * o] = INFINITY; box[4 * o + 1] = -INFINITY; box[4 * o + 2] = INFINITY; box[4 * o + 3] = -INFINITY; }
         for (int o = 0; o < n_obst; o++) {
             double xlo = -INFINITY, xhi = INFINITY, ylo = -INFINITY, yhi = INFINITY;
             for (int r = hp_off[o]; r < hp_off[o + 1]; r++) {

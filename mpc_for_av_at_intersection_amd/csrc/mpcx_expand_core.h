@@ -242,11 +242,30 @@ __device__ __forceinline__ void expand_records_coop(const ExpandArgs &a, const T
         // which is what bounds it (109 LDS instructions per wavefront, 1.6e7 per launch)
         typedef const __attribute__((address_space(4))) double cdouble;     // constant address space: read-only for the kernel's lifetime
         cdouble *gbox = (cdouble *)a.aabb;
-#pragma unroll 8
-        for (int j = 0; j < on; j++) {
+        // four boxes per batch of scalar loads (the table is padded to a multiple of four with boxes nothing reaches); per box the four
+        // compares narrow EXEC one after the other (v_cmpx), the lanes that are left set their candidate bit, EXEC is restored: 5 vector
+        // + 2 scalar instructions per obstacle where the compiler's and-tree of four compare masks took 6 + 8.  !(a > b) forms throughout,
+        // so a NaN coordinate keeps the obstacle (as the plain expression `!(xmin > bx1 | ...)` does).
+        for (int j = 0; j < on; j += 4) {
             cdouble *bx = gbox + 4 * (o0 + j);
-            const unsigned out = (unsigned)(xmin > bx[1]) | (unsigned)(xmax < bx[0]) | (unsigned)(ymin > bx[3]) | (unsigned)(ymax < bx[2]);
-            cand |= (out ^ 1u) << j;
+            double b[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) b[q] = bx[q];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "v_cmpx_nlt_f64 vcc, %[b1], %[xmin]\n\t"
+                             "v_cmpx_ngt_f64 vcc, %[b0], %[xmax]\n\t"
+                             "v_cmpx_nlt_f64 vcc, %[b3], %[ymin]\n\t"
+                             "v_cmpx_ngt_f64 vcc, %[b2], %[ymax]\n\t"
+                             "v_or_b32 %[cand], %[bit], %[cand]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [cand] "+v"(cand), [sv] "=&s"(saved)
+                             : [b0] "s"(b[4 * q]), [b1] "s"(b[4 * q + 1]), [b2] "s"(b[4 * q + 2]), [b3] "s"(b[4 * q + 3]),
+                               [xmin] "v"(xmin), [xmax] "v"(xmax), [ymin] "v"(ymin), [ymax] "v"(ymax), [bit] "s"(1u << (j + q))
+                             : "vcc");
+            }
         }
         if (!live) cand = 0;
         // queue positions: exclusive prefix of the candidate counts over the lanes
