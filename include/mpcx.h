@@ -180,6 +180,15 @@ typedef struct {
     double dt, L, radius;
     double circle_centers[4]; /* (x,y) of the 2 discs, car_dimensions.py:61-79 */
     double max_accel, max_speed;
+    /* optional (NULL = off): per point of the path table, the arc length from the first point of ITS path (any running sum whose
+     * differences inside one path are arc lengths will do), and a bound on how far such a difference can be from the reference's own
+     * np.cumsum over the same steps (trajectories.py:72-79; a few n * 2^-53 * length: the host knows n and the length).  Paths are
+     * constants of a run while every step of every agent re-derives step lengths and their running sum from the points: with the table
+     * mpcx_interaction_batch takes floor(c_i / dl_i) from differences of its entries wherever c_i / dl_i is farther from an integer than
+     * that bound (+ rounding) can move it, and falls back to the sequential sum over the points for an agent with a closer call --
+     * identical outputs either way. */
+    const double *path_cum;
+    double path_cum_err;
 } mpcx_interaction_params;
 int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip, int32_t P,
                                const double *state /*P,4*/,

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .runtime import Context, InteractionParams, MpcParams, MpcxError
+from .runtime import path_tables, Context, InteractionParams, MpcParams, MpcxError
 
 
 class IntersectionBatch:
@@ -33,8 +33,9 @@ class IntersectionBatch:
         all-gather of 6-double agent states per step.  `exchange` says who moves the rows: 'rccl' (mpcx_allgather_states
         on the context's communicator, inside mpcx_closed_loop_run) or a callable local(B, A_loc, 6) -> pool(B, A, 6)
         (sharding.torch_exchange: torch.distributed, used for gloo rehearsals)."""
+        # (a copy: the arc-length table below belongs to THIS batch's paths)
+        ip = dataclasses.replace(ip, max_path_len=max(int(ip.max_path_len), max(len(r) for r in routes)))     # sizes the interaction kernel's LDS
         self.ctx, self.params, self.ip, self.dl = ctx, params, ip, float(dl)
-        ip.max_path_len = max(int(ip.max_path_len), max(len(r) for r in routes))     # sizes the interaction kernel's LDS
         ctx.set_mpc_params(params)
         route_of_agent = np.asarray(route_of_agent, dtype=np.int64)
         start_index = np.asarray(start_index, dtype=np.int64)
@@ -60,6 +61,11 @@ class IntersectionBatch:
         table = np.concatenate(routes, axis=0).astype(np.float64)
         self.path = ctx.f64(table)
         self.path_cs = ctx.f64(np.column_stack([np.cos(table[:, 2]), np.sin(table[:, 2])]))
+        # paths are constants of the run: their arc lengths are summed once here instead of by every agent in every step (the conflict
+        # search takes its resampling buckets from this table wherever that is safe, mpcx_interaction_params.path_cum)
+        cum, cum_err = path_tables(table, offs)
+        self.path_cum = ctx.f64(cum)
+        ip.path_cum, ip.path_cum_err = self.path_cum, cum_err
         r = route_of_agent.reshape(-1)
         s = start_index.reshape(-1)
         self.path_off = ctx.i32(offs[r])

@@ -299,9 +299,13 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     // Each point is loaded once (the predecessor comes from the neighbour lane), the next 64 points are in flight while
     // the current ones are worked on, and the ego distance takes its square root only where the squared distance could
     // enter the lane's three smallest (sqrt is monotone, so a larger square cannot give a smaller distance).
+    // With the caller's arc-length table (mpcx_interaction_params.path_cum) the step lengths are not needed here at all -- no
+    // square root, no neighbour shuffles, nothing stored -- and an agent that does not advance skips the pass.
+    const double *cumtab = ip.path_cum ? ip.path_cum + (size_t)a.path_off[p] : nullptr;
+    const bool tab = cumtab != nullptr;
     double b0d = INFINITY, b1d = INFINITY, b2d = INFINITY, b0s = INFINITY, b1s = INFINITY, b2s = INFINITY;
     int b0i = 0x7fffffff, b1i = 0x7fffffff, b2i = 0x7fffffff;
-    {
+    if (!tab || advance) {
         // the points arrive in batches of DEPTH x 64: the loads of the next batch are all in flight while this one is worked on (one
         // batch deep the pass waited for an L2 round trip per 64 points: it is bound by its loads, not by its arithmetic)
         constexpr int DEPTH = 4;
@@ -326,11 +330,13 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
             for (int k = 0; k < DEPTH; k++) {
                 const int i = i0 + k * WAVE + lane;
                 const double px = bx[k], py = by[k];
-                double qx = __shfl_up(px, 1, WAVE), qy = __shfl_up(py, 1, WAVE);
-                if (lane == 0) { qx = lastx; qy = lasty; }
-                lastx = rdlane(px, WAVE - 1); lasty = rdlane(py, WAVE - 1);
+                if (!tab) {
+                    double qx = __shfl_up(px, 1, WAVE), qy = __shfl_up(py, 1, WAVE);
+                    if (lane == 0) { qx = lastx; qy = lasty; }
+                    lastx = rdlane(px, WAVE - 1); lasty = rdlane(py, WAVE - 1);
+                    if (i < n_old) s_cum[i] = (i == 0) ? 0.0 : dist2d(px, py, qx, qy);
+                }
                 if (i < n_old) {
-                    s_cum[i] = (i == 0) ? 0.0 : dist2d(px, py, qx, qy);
                     if (advance) {
                         const double dx = __dadd_rn(px, -x), dy = __dadd_rn(py, -y);
                         const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
@@ -431,7 +437,12 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
         __syncthreads();
     };
     // bucket of every point, keep the points where the bucket advances (+ first and last); returns the number kept
+    const double cum0 = tab ? cumtab[tidx] : 0.0;
+    const double inv_const = frcp(dl_const);
+    const double marg = tab ? ip.path_cum_err + 1e-13 : 1.01e-10;     // how far the fast running sum can be from np.cumsum's
     auto resample = [&](bool check, bool &unsure) -> int {
+        // check = true: the fast pass -- running sums from the table (or the parallel scan), quotient by reciprocal (<= 2 ulp from the
+        // division), bucket accepted only outside the margin; check = false: np.cumsum's own sums (prefix_exact) and the division
         int base = 0;
         long long q_carry = 0;                // bucket of the last element of the previous 64-block
         unsure = false;
@@ -439,17 +450,18 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
             const int i = i0 + lane;
             long long q = 0;
             if (i < n) {
-                double dl = dl_const;
+                double dl = dl_const, inv = inv_const;
                 if (accel_phase) {
                     const double r = __dadd_rn(__dmul_rn(ip.max_accel, (double)(i + 1)), v);   // cumsum of equal terms (exact for 2.0) + v
                     dl = __dmul_rn(ip.dt, fmin(r, ip.max_speed));
+                    if (check) inv = frcp(dl);
                 }
-                const double c = s_cum[shift + i];
-                const double r = __ddiv_rn(c, dl);
+                const double c = (check && tab) ? cumtab[tidx + i] - cum0 : s_cum[shift + i];
+                const double r = check ? c * inv : __ddiv_rn(c, dl);
                 q = (long long)floor(r);
-                if (check && c != 0.0) {          // c == 0 is exact in both summation orders
+                if (check && c != 0.0) {          // c == 0 is exact in every summation order
                     const double room = fabs(r - rint(r));
-                    if (!(dl > 0.0) || !(room > 1.01e-10 / dl + 1e-15 * fabs(r))) unsure = true;
+                    if (!(dl > 0.0) || !(room > marg * inv + 2e-15 * fabs(r))) unsure = true;
                 }
             }
             long long qprev = __shfl_up(q, 1, WAVE);
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
         }
         return base;
     };
-    prefix_fast();
+    if (!tab) prefix_fast();
     __syncthreads();
     ISTAMP(2);      // cumulative lengths
     bool unsure;

@@ -4,7 +4,7 @@ GPU or without the built library raises."""
 import ctypes as C
 import functools
 from dataclasses import dataclass, field
-from typing import Optional, Sequence
+from typing import Tuple, Optional, Sequence
 
 import numpy as np
 import torch
@@ -77,6 +77,8 @@ class InteractionParams:
     max_accel: float = 2.0
     max_speed: float = 30.0 / 3.6
     max_path_len: int = 0        # longest path of the batch in points (0 = the kernel's default capacity of 1024)
+    path_cum: Optional[torch.Tensor] = None    # per point of the path table: arc length from the start of its path (device, float64) ...
+    path_cum_err: float = 0.0                  # ... and the bound on the error of its differences (see mpcx_interaction_params; `path_tables()`)
 
     def to_c(self) -> _lib.InteractionParamsC:
         p = _lib.InteractionParamsC()
@@ -92,11 +94,33 @@ class InteractionParams:
             raise MpcxError('car_dimensions.circle_centers must hold one or two discs (x, y offsets), got %d numbers' % len(cc))
         p.circle_centers[:] = cc
         p.max_accel, p.max_speed = float(self.max_accel), float(self.max_speed)
+        p.path_cum = None if self.path_cum is None else C.c_void_p(self.path_cum.data_ptr())
+        p.path_cum_err = float(self.path_cum_err) if self.path_cum is not None else 0.0
         return p
 
 
 class MpcxError(RuntimeError):
     pass
+
+
+def path_tables(table: np.ndarray, offs) -> Tuple[np.ndarray, float]:
+    """Arc-length table for mpcx_interaction_params.path_cum: for the concatenated path table `table` ((n, >= 2): x, y, ...) whose
+    paths start at offs[0], offs[1], ... (offs[-1] = n), per point the running sum of the step lengths of ITS path (np.cumsum, restarted
+    per path) and the bound on the distance between a difference of two entries and the reference's own running sum over the same steps
+    (trajectories.py:72-79): both are sequential float64 sums of at most n_max non-negative terms adding up to at most L, each within
+    (n_max - 1) * 2^-53 * L of the exact sum (first-order bound, doubled here), plus one rounding of the subtraction."""
+    table = np.asarray(table, dtype=np.float64)
+    cum = np.zeros(len(table))
+    worst = 0.0
+    for a, b in zip(offs[:-1], offs[1:]):
+        if b - a < 1:
+            continue
+        d = table[a + 1:b, :2] - table[a:b - 1, :2]
+        steps = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+        cum[a + 1:b] = np.cumsum(steps)
+        n, length = b - a, float(cum[b - 1]) if b - a > 1 else 0.0
+        worst = max(worst, 2.0 * (3 * n + 2) * 2.0 ** -53 * length)
+    return cum, worst
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -316,6 +340,8 @@ class Context:
         self._want(path_cs, torch.float64, (path.shape[0], 2), 'path_cs')
         for nm, t in (('path_off', path_off), ('path_len', path_len), ('obs_off', obs_off), ('obs_cnt', obs_cnt), ('traj_idx', traj_idx)):
             self._want(t, i32, (Pn,), nm)
+        if ip.path_cum is not None:
+            self._want(ip.path_cum, torch.float64, (path.shape[0],), 'path_cum')
         nobs = 0 if obs6 is None else obs6.shape[0]
         if out is None:
             out = dict(hit_idx=torch.empty(Pn, dtype=i32, device=self.device),
