@@ -451,12 +451,14 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
             long long q = 0;
             if (i < n) {
                 double dl = dl_const, inv = inv_const;
-                if (accel_phase) {
+                // the predicted speed v + a (i + 1) is monotone in i: once the FIRST point of a 64-point block has reached max_speed every
+                // later one has, and dl is the constant (a car needs four points for that: only the first block takes this branch)
+                if (accel_phase && (!(ip.max_accel >= 0.0) || __dadd_rn(__dmul_rn(ip.max_accel, (double)(i0 + 1)), v) < ip.max_speed)) {
                     const double r = __dadd_rn(__dmul_rn(ip.max_accel, (double)(i + 1)), v);   // cumsum of equal terms (exact for 2.0) + v
                     dl = __dmul_rn(ip.dt, fmin(r, ip.max_speed));
                     if (check) inv = frcp(dl);
                 }
-                const double c = (check && tab) ? cumtab[tidx + i] - cum0 : s_cum[shift + i];
+                const double c = s_cum[shift + i];
                 const double r = check ? c * inv : __ddiv_rn(c, dl);
                 q = (long long)floor(r);
                 if (check && c != 0.0) {          // c == 0 is exact in every summation order
@@ -475,7 +477,15 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
         }
         return base;
     };
-    if (!tab) prefix_fast();
+    if (tab) {      // running sums from the table, four batches of loads in flight (one by one the pass waited a memory round trip per 64 points)
+        for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
+            double t[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int i = i0 + k * WAVE + lane; t[k] = cumtab[tidx + (i < n ? i : 0)]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int i = i0 + k * WAVE + lane; if (i < n) s_cum[shift + i] = t[k] - cum0; }
+        }
+    } else prefix_fast();
     __syncthreads();
     ISTAMP(2);      // cumulative lengths
     bool unsure;

@@ -139,7 +139,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
         }
         if (!ctx->bins_clean) {
             if (hipMemsetAsync(ctx->bins, 0, (size_t)MPCX_ORDER_COPIES * MPCX_ORDER_BINS * sizeof(int32_t), ctx->stream) != hipSuccess ||
-                hipMemsetAsync(ctx->ticket, 0, sizeof(int32_t), ctx->stream) != hipSuccess)
+                hipMemsetAsync(ctx->ticket, 0, MPCX_TICKET_WORDS * sizeof(int32_t), ctx->stream) != hipSuccess)
                 return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: hipMemsetAsync failed");
             ctx->bins_clean = true;
         }
@@ -178,6 +178,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     memcpy(key + o, &ctx->prev_cut, sizeof ctx->prev_cut); o += sizeof ctx->prev_cut;
     memcpy(key + o, &ctx->bins, sizeof ctx->bins); o += sizeof ctx->bins;
     memcpy(key + o, &ctx->qp_solver, sizeof ctx->qp_solver); o += sizeof ctx->qp_solver;      // the captured launch is the solver chosen at capture time
+    memcpy(key + o, &ctx->handoff_iters, sizeof ctx->handoff_iters); o += sizeof ctx->handoff_iters;
     memcpy(key + o, &ctx->lin_passes, sizeof ctx->lin_passes); o += sizeof ctx->lin_passes;
     memcpy(key + o, &ctx->stats, sizeof ctx->stats);
     if (!ctx->loop_exec || memcmp(key, ctx->loop_key, sizeof key) != 0) {

@@ -156,7 +156,7 @@ struct PlantArgs {
 __global__ __launch_bounds__(256) void plant_kernel(PlantArgs a) {
     if (a.zero_bins && blockIdx.x == 0) {
         for (int i = threadIdx.x; i < MPCX_ORDER_COPIES * MPCX_ORDER_BINS; i += blockDim.x) a.zero_bins[i] = 0;
-        if (threadIdx.x == 0) *a.zero_ticket = 0;
+        if (threadIdx.x < MPCX_TICKET_WORDS) a.zero_ticket[threadIdx.x] = 0;
     }
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (a.has_stats) {          // run statistics (mpcx_closed_loop_stats)

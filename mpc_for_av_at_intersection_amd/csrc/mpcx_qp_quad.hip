@@ -56,6 +56,10 @@ struct GroupCx {
     // dev build: shader-clock time per phase, summed per wavefront (lane 0 adds to prof[phase] at the end)
     unsigned long long t_last = 0, t_acc[10] = {};
     __device__ __forceinline__ void stamp(int k) { const unsigned long long t = __builtin_amdgcn_s_memtime(); if (t_last) t_acc[k] += t - t_last; t_last = t; }
+    unsigned char *occ = nullptr;        // dev build: per wavefront 64 rounds x (groups at work, of which in a trial / polish round)
+    unsigned char *life = nullptr;       // dev build: per problem (round it was drawn in, round it was handed in: + 100 = handed over)
+    __device__ __forceinline__ void lifetime(int b, int which, int round) { if (q == 0 && life) life[2 * b + which] = (unsigned char)round; }
+    __device__ __forceinline__ void occupancy(int round, int groups, int special) { if (lane == 0 && occ && round < 64) { occ[2 * round] = (unsigned char)groups; occ[2 * round + 1] = (unsigned char)special; } }
 #else
     __device__ __forceinline__ void stamp(int) const {}
 #endif
@@ -93,6 +97,38 @@ struct QueueSrc {
 #endif
     __device__ __forceinline__ int refill_min() const { return MPCX_REFILL_GROUPS * LQ; }   // in lanes
     __device__ __forceinline__ long max_rounds() const { return ((long)a.B + 2) * (long)(a.p.max_iter + 6) * (MPCX_POLISH_TRIES + 1); }
+    // ---- hybrid launch (QpArgs::hand_*): problems that have reached hand_iters iterations go to the condensed solver's wavefronts
+    __device__ __forceinline__ bool handoff_on() const { return a.hand_mode == 1; }
+    __device__ __forceinline__ int handoff_iters() const { return a.hand_iters; }
+    __device__ __forceinline__ int rec_stride() const { return 18 * a.p.T + 2; }
+    template <class Cx>
+    __device__ __forceinline__ int handoff_slot(Cx &cx, bool hand) const {      // the group's record slot (leader draws, group sum broadcasts)
+        int sl = 0;
+        if (hand && cx.q == 0) sl = atomicAdd(a.hand_ctl, 1) + 1;
+        sl = (int)cx.gsum((double)sl) - 1;
+        return (hand && sl < a.hand_cap) ? sl : -1;
+    }
+    __device__ __forceinline__ double *handoff_record(int slot) const { return a.hand_rec + (size_t)slot * rec_stride(); }
+    template <class Cx>
+    __device__ __forceinline__ void handoff_publish(Cx &cx, bool go, int slot, int pbi, int it, int loose_run, int ptested) const {
+        if (go && cx.q == 0) {
+            int32_t *meta = reinterpret_cast<int32_t *>(handoff_record(slot) + 18 * a.p.T);
+            meta[0] = pbi; meta[1] = it; meta[2] = loose_run; meta[3] = ptested;
+            a.status[pbi] = MPCX_QP_NUMERIC;          // until the receiver reports: a record nobody picks up reads as a failed solve
+            a.iters[pbi] = it;
+        }
+        if (a.hand_live) {
+            __threadfence();                              // the group's record is visible before its flag
+            if (go && cx.q == 0) __hip_atomic_store(a.hand_ready + slot, a.hand_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    template <class Cx>
+    __device__ __forceinline__ void finish(Cx &cx) const {                      // this wavefront writes no more records
+        if (a.hand_mode == 1 && a.hand_live) {
+            __threadfence();
+            if (cx.lane == 0) __hip_atomic_fetch_add(a.hand_ctl + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     template <class Cx>
     __device__ __forceinline__ bool fetch(Cx &cx, mpcx_mpc_params &P, int &pbi) const {
         int t = 0;
@@ -122,20 +158,28 @@ __global__ __launch_bounds__(64, 1) void qp_quad_kernel(QpArgs a) {
 #ifdef MPCX_STAGE_TRACE
     if (blockIdx.x == 0) cx.trace_buf = a.kkt + 4 * (size_t)a.B;
 #endif
+#ifdef MPCX_STAGE_PROFILE
+    cx.occ = (unsigned char *)(a.kkt + 4 * (size_t)a.B + 16) + 128 * (size_t)blockIdx.x;      // dev build only: needs 16 + 16 * grid spare doubles behind kkt
+    cx.life = (unsigned char *)(a.kkt + 4 * (size_t)a.B + 16 + 16 * 1024);                   // ... and B / 4 more behind those (grid <= 1024)
+#endif
     mpcx_stage::solve_queue(cx, src);
 #ifdef MPCX_STAGE_PROFILE
     if (lane == 0) for (int k = 0; k < 10; k++) atomicAdd((unsigned long long *)(a.kkt + 4 * (size_t)a.B) + k, cx.t_acc[k]);   // dev build only: needs 10 spare slots behind kkt
 #endif
 }
 
-template <int LQ, int SPL, bool JERK>
-void launch_qp_group(const QpArgs &a, hipStream_t st, int n_cu) {
-    const int per_wave = 64 / LQ;
-    const int need = (a.B + per_wave - 1) / per_wave;
+int qp_stage_grid(int B, int n_cu) {
+    const int need = (B + 7) / 8;       // eight lane groups per wavefront
     // one wavefront per SIMD; MPCX_QP_GRID_DIV=d (dev aid: several shards in flight on separate streams, each on 1/d of the chip)
     static const int grid_div = [] { const char *e = getenv("MPCX_QP_GRID_DIV"); const int d = e ? atoi(e) : 1; return d >= 1 && d <= 16 ? d : 1; }();
     const int resident = n_cu * 4 / grid_div;
-    const int grid = need < resident ? need : resident;
+    return need < resident ? need : resident;
+}
+
+template <int LQ, int SPL, bool JERK>
+void launch_qp_group(const QpArgs &a, hipStream_t st, int n_cu) {
+    static_assert(LQ == 8, "qp_stage_grid counts eight lane groups per wavefront");
+    const int grid = qp_stage_grid(a.B, n_cu);
     if (a.has_tune) hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, true, JERK>), dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((qp_quad_kernel<LQ, SPL, false, JERK>), dim3(grid), dim3(64), 0, st, a);
 }
