@@ -322,14 +322,6 @@ int32_t mpcx_qp_set_order_hint(mpcx_ctx *ctx, const int32_t *prev_iters /*B or N
  * Same problem, same iteration, same exit rules: the choice changes speed, not results (agreement <= 1e-9 is tested).  The
  * environment variable MPCX_QP_KERNEL=wave|stage sets the default of new contexts. */
 int32_t mpcx_set_qp_solver(mpcx_ctx *ctx, int32_t which);
-/* Large batches on the stage-structured solver run as a HYBRID launch (round 3): a problem that reaches `iterations` interior-point
- * iterations leaves the stage solver (eight problems per wavefront, 40 us per iteration) for a wavefront of the condensed solver (one problem,
- * 9-13 us per iteration), which runs on the SIMDs the stage solver's wavefronts give up as its queue runs dry -- the launch no longer
- * ends with a handful of wavefronts grinding through its longest problems at 40 us per iteration.  The rule is per problem (no timing
- * in it): results are reproducible, iteration counts unchanged, solutions within 1e-9 of the single-solver launch.
- * iterations: -1 = default (8, or the environment variable MPCX_QP_HANDOFF), 0 = off. */
-#define MPCX_QP_MAX_ITER_CAP 1000
-int32_t mpcx_set_qp_handoff(mpcx_ctx *ctx, int32_t iterations);
 
 /* ---- measurement hook: while enabled, every mpcx_qp_solve_batch launch (direct or through mpcx_closed_loop_run
  * without a graph) is bracketed by a pair of HIP events on the context's stream.  mpcx_profile_qp_read waits for

@@ -63,7 +63,7 @@ EXPORTS = ['mpcx_create', 'mpcx_destroy', 'mpcx_last_error', 'mpcx_version', 'mp
            'mpcx_qp_solve_batch', 'mpcx_mpc_prepare_batch', 'mpcx_search_model_create', 'mpcx_search_model_destroy',
            'mpcx_expand_batch', 'mpcx_interaction_batch', 'mpcx_moving_collision_batch', 'mpcx_plant_step_batch',
            'mpcx_transform_batch', 'mpcx_cutoff_index_batch', 'mpcx_predict_obstacles_batch', 'mpcx_selftest_wave_ops', 'mpcx_selftest_mfma',
-           'mpcx_closed_loop_run', 'mpcx_profile_qp', 'mpcx_profile_qp_read', 'mpcx_set_instance_tuning', 'mpcx_set_qp_solver', 'mpcx_set_qp_handoff', 'mpcx_qp_set_order_hint', 'mpcx_expand_multi_batch',
+           'mpcx_closed_loop_run', 'mpcx_profile_qp', 'mpcx_profile_qp_read', 'mpcx_set_instance_tuning', 'mpcx_set_qp_solver', 'mpcx_qp_set_order_hint', 'mpcx_expand_multi_batch',
            'mpcx_comm_unique_id', 'mpcx_comm_init', 'mpcx_comm_destroy', 'mpcx_allgather_states', 'mpcx_closed_loop_stats',
            'mpcx_mpc_prepare_batch_ov', 'mpcx_set_linearisation_passes', 'mpcx_astar_batch']
 
@@ -116,7 +116,6 @@ def load():
     lib.mpcx_profile_qp_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.mpcx_set_instance_tuning.restype = i32; lib.mpcx_set_instance_tuning.argtypes = [vp, vp, i32]
     lib.mpcx_set_qp_solver.restype = i32; lib.mpcx_set_qp_solver.argtypes = [vp, i32]
-    lib.mpcx_set_qp_handoff.restype = i32; lib.mpcx_set_qp_handoff.argtypes = [vp, i32]
     lib.mpcx_qp_set_order_hint.restype = i32; lib.mpcx_qp_set_order_hint.argtypes = [vp, vp, vp, vp]
     lib.mpcx_expand_multi_batch.restype = i32; lib.mpcx_expand_multi_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.mpcx_comm_unique_id.restype = i32; lib.mpcx_comm_unique_id.argtypes = [vp]

@@ -74,8 +74,6 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
-    if (ctx->hand_rec) (void)hipFree(ctx->hand_rec);
-    if (ctx->hand_ready) (void)hipFree(ctx->hand_ready);
     if (ctx->bins) (void)hipFree(ctx->bins);
     if (ctx->pred) (void)hipFree(ctx->pred);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
@@ -124,13 +122,6 @@ int32_t mpcx_set_qp_solver(mpcx_ctx *ctx, int32_t which) {
     if (!ctx) return MPCX_E_INVALID;
     if (which < 0 || which > 2) return mpcx_fail(ctx, MPCX_E_INVALID, "set_qp_solver: 0 (automatic), 1 (condensed) or 2 (stage-structured)");
     ctx->qp_solver = which;
-    return MPCX_OK;
-}
-
-int32_t mpcx_set_qp_handoff(mpcx_ctx *ctx, int32_t iterations) {
-    if (!ctx) return MPCX_E_INVALID;
-    if (iterations < -1 || iterations > MPCX_QP_MAX_ITER_CAP) return mpcx_fail(ctx, MPCX_E_INVALID, "set_qp_handoff: -1 (default), 0 (off) or an iteration count");
-    ctx->handoff_iters = iterations;
     return MPCX_OK;
 }
 

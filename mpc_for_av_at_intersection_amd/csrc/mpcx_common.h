@@ -10,10 +10,7 @@ struct mpcx_ctx {
     hipStream_t stream;
     mpcx_mpc_params mpc;
     bool have_mpc;
-    int32_t *ticket;     // device words: [0] work-queue head of the persistent QP kernel, [1..3] counters of the hybrid launch (QpArgs::hand_ctl); 8 allocated
-    double *hand_rec = nullptr; size_t hand_cap = 0;     // hand-over records of the hybrid launch (capacity in problems)
-    int32_t *hand_ready = nullptr; int hand_gen = 0;     // concurrent form: per-record flags and the launch generation they are stamped with
-    int handoff_iters = -1;    // mpcx_set_qp_handoff: iterations after which the stage solver hands a problem over; 0 = off; -1 = default (MPCX_QP_HANDOFF or 8)
+    int32_t *ticket;     // device words: [0] work-queue head of the persistent QP kernel, [4] the list of problems the condensed solver gives up on, [5] the head of the launch that works that list off; 8 allocated
     int n_cu;            // compute units of the device
     double *pred;        // scratch: predicted obstacle disc centres [NOBS][steps][2 discs][2]
     size_t pred_cap;     // capacity of pred in doubles
@@ -71,7 +68,7 @@ int32_t mpcx_ensure_ticket(mpcx_ctx *ctx);                      // work-queue wo
 #define MPCX_JUMP_BONUS 11
 #endif
 #define MPCX_ORDER_BINS 64
-#define MPCX_TICKET_WORDS 8      /* ctx->ticket: the queue head + the hybrid launch's counters, zeroed together */
+#define MPCX_TICKET_WORDS 8      /* ctx->ticket: the queue head and the other per-launch counters, zeroed together */
 #define MPCX_ORDER_COPIES 16
 namespace mpcx {
 __device__ __forceinline__ int order_key_of(int hint, bool moved) {
@@ -139,17 +136,6 @@ struct QpArgs {
     int32_t *fail_list, *fail_count;
     const int32_t *queue_len;
     int has_queue_len;
-    // hybrid launch (mpcx_qp_solve_batch): the stage solver (hand_mode 1) leaves the problems that reach `hand_iters` iterations as
-    // records; a launch of the condensed solver (hand_mode 2) right behind it finishes them, one problem per wavefront -- a third of the
-    // time per iteration, on a chip that is free again.  Record of slot j at hand_rec + j * (18 T + 2) doubles: u [2][T] | slacks [T][8] |
-    // multipliers [T][8] | (problem, it, loose_run, ptested) as four int32.  hand_ctl: [0] records written, [1] tickets of the second phase.
-    int hand_mode, hand_iters, hand_cap;
-    double *hand_rec;
-    int32_t *hand_ctl;
-    // concurrent form (hand_live): the second phase runs BESIDE the stage solver on a few SIMDs (side stream) and polls for records:
-    // hand_ready[j] == hand_gen marks record j of this launch complete, hand_ctl[2] counts the stage wavefronts that have left (of hand_grid)
-    int hand_live, hand_gen, hand_grid;
-    int32_t *hand_ready;
 };
 
 void launch_qp_stage(const QpArgs &a, hipStream_t st, int n_cu);   // mpcx_qp_quad.hip

@@ -178,7 +178,6 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     memcpy(key + o, &ctx->prev_cut, sizeof ctx->prev_cut); o += sizeof ctx->prev_cut;
     memcpy(key + o, &ctx->bins, sizeof ctx->bins); o += sizeof ctx->bins;
     memcpy(key + o, &ctx->qp_solver, sizeof ctx->qp_solver); o += sizeof ctx->qp_solver;      // the captured launch is the solver chosen at capture time
-    memcpy(key + o, &ctx->handoff_iters, sizeof ctx->handoff_iters); o += sizeof ctx->handoff_iters;
     memcpy(key + o, &ctx->lin_passes, sizeof ctx->lin_passes); o += sizeof ctx->lin_passes;
     memcpy(key + o, &ctx->stats, sizeof ctx->stats);
     if (!ctx->loop_exec || memcmp(key, ctx->loop_key, sizeof key) != 0) {

@@ -141,45 +141,11 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     const int lane = threadIdx.x;
   for (int guard = 0; guard <= a.B; guard++) {      // every wavefront leaves after at most B+1 tickets (bounded by construction)
     int b = 0;
-    const double *rec = nullptr;          // hybrid launch: the iterate the stage solver handed over
-    if (a.hand_mode == 2) {
-        // second phase of the hybrid launch: the records the stage solver left behind (their number is final: this launch follows it
-        // in the stream), one per wavefront
-        int my = 0;
-        if (lane == 0) my = atomicAdd(a.hand_ctl + 1, 1);
-        my = __builtin_amdgcn_readfirstlane(my);
-        if (!a.hand_live) {
-            const int cnt = a.hand_ctl[0] < a.hand_cap ? a.hand_ctl[0] : a.hand_cap;
-            if (my >= cnt) break;
-        } else {
-            // concurrent form: wait until the stage solver has filled slot `my` -- or until all its wavefronts have left and the slot lies
-            // beyond the last record.  Bounded (about two seconds of polling): a record nobody picks up keeps its failure status.
-            if (my >= a.hand_cap) break;
-            int go = 0;
-            if (lane == 0) {
-                for (int spin = 0; spin < (1 << 21); spin++) {
-                    if (__hip_atomic_load(a.hand_ready + my, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.hand_gen) { go = 1; break; }
-                    if (__hip_atomic_load(a.hand_ctl + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= a.hand_grid) {
-                        if (my >= __hip_atomic_load(a.hand_ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
-                        if (__hip_atomic_load(a.hand_ready + my, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.hand_gen) { go = 1; break; }
-                    }
-                    __builtin_amdgcn_s_sleep(16);
-                }
-            }
-            go = __builtin_amdgcn_readfirstlane(go);
-            if (!go) break;
-            __threadfence();
-        }
-        rec = a.hand_rec + (size_t)my * (18 * a.p.T + 2);
-        b = reinterpret_cast<const int32_t *>(rec + 18 * a.p.T)[0];
-        b = __builtin_amdgcn_readfirstlane(b);
-    } else {
-        if (lane == 0) b = atomicAdd(a.ticket, 1);
-        b = __builtin_amdgcn_readfirstlane(b);
-        if (b >= a.B) break;
-        if (a.has_order) b = a.order[b];      // hardest first (mpcx_qp_set_order_hint): a wavefront that draws a long problem draws nothing
-                                              // else while the short ones are shared out among the others
-    }
+    if (lane == 0) b = atomicAdd(a.ticket, 1);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= a.B) break;
+    if (a.has_order) b = a.order[b];      // hardest first (mpcx_qp_set_order_hint): a wavefront that draws a long problem draws nothing
+                                          // else while the short ones are shared out among the others
     lds_sync();                       // the previous problem's LDS reads are done before this one overwrites the tables
     mpcx_mpc_params P = a.p;
     if (a.has_tune) {                 // wave-uniform row (b comes from readfirstlane): scalar loads
@@ -424,26 +390,7 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     // (pm0..pm3: this lane's four rows) and lam_e + rho gap as their linear term; accepted if its end point is a KKT point
     bool polish = false, pol_pred = false, pm0 = false, pm1 = false, pm2 = false, pm3 = false;
     int ptries = 0, pend = 0, ptested = -1;
-    int it0 = 0;
-    if (rec) {
-        // the stage solver's iterate (its rows: stage t holds +-a_t, +-delta_t, +-(delta_t - delta_{t-1}), +-v_{t+1}; this lane owns the box
-        // rows of its unknown and, accel lane k: the speed rows of stage k, steer lane k: the rate rows of stage k + 1)
-        const int32_t *meta = reinterpret_cast<const int32_t *>(rec + 18 * T);
-        it0 = meta[1]; loose_run = meta[2]; ptested = meta[3];
-        trial = false;
-        const double *S = rec + 2 * T, *L = rec + 2 * T + 8 * T;
-        if (real) {
-            u = rec[kind * T + k];
-            const int r01 = kind ? 2 : 0;
-            s0 = S[8 * k + r01]; s1 = S[8 * k + r01 + 1]; l0 = L[8 * k + r01]; l1 = L[8 * k + r01 + 1];
-            if (val23) {
-                const int t23 = kind ? k + 1 : k, r23 = kind ? 4 : 6;
-                s2 = S[8 * t23 + r23]; s3 = S[8 * t23 + r23 + 1]; l2 = L[8 * t23 + r23]; l3 = L[8 * t23 + r23 + 1];
-            }
-        }
-    }
-
-    for (it = it0; it <= max_iter; it++) {
+    for (it = 0; it <= max_iter; it++) {
         // -------- H u from the PRISTINE Hessian (restore the band entries the previous iteration patched)
         sh.H[i_d] = h_d; sh.H[i_hi] = h_hi; sh.H[i_lo] = h_lo;
         sh.ub[lane] = u;
@@ -770,7 +717,7 @@ __global__ __launch_bounds__(ORDER_BLOCK) void qp_order_hist_kernel(int B, const
 __global__ __launch_bounds__(ORDER_BLOCK) void qp_order_scatter_kernel(int B, const int32_t *hint, const int32_t *now, const int32_t *prev,
                                                                        const int32_t *block_hist, int32_t *order, int32_t *ticket) {
     __shared__ int32_t total[ORDER_BINS], base[ORDER_BINS], h[ORDER_BINS], part_all[ORDER_BLOCK], part_before[ORDER_BLOCK];
-    if (blockIdx.x == 0 && threadIdx.x < MPCX_TICKET_WORDS) ticket[threadIdx.x] = 0;      // the queue head and the hybrid launch's counters
+    if (blockIdx.x == 0 && threadIdx.x < MPCX_TICKET_WORDS) ticket[threadIdx.x] = 0;      // the queue head and the other per-launch counters
     {       // thread (part, bin) adds up every (ORDER_BLOCK / ORDER_BINS)-th block histogram: the loads of a thread are independent
         const int k = threadIdx.x % ORDER_BINS;
         int all = 0, before = 0;
@@ -880,45 +827,6 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
         // works it off are words 4 and 5 of the context's counters (zeroed with the queue head)
         a.defer_fail = 1; a.fail_list = order_fail_list(ctx, (size_t)B); a.fail_count = ctx->ticket + 4;
     }
-    // ---- hybrid launch: the stage solver hands the problems that reach `hand` iterations over to wavefronts of the condensed solver,
-    // which take the SIMDs the stage solver's wavefronts leave as its queue runs dry.  Measured on the benchmark launch (scripts/
-    // stage_occupancy.py): all 1024 wavefronts are busy for 10-11 rounds of 40 us, then 7-8 more rounds pass with a few dozen of them
-    // alive, each holding one or two 10-15-iteration problems; the condensed solver takes 9-13 us per iteration of ONE problem.  The
-    // rule is per problem and does not depend on timing, so results are reproducible; iterates are the same (same iteration, other
-    // linear algebra: 1e-12).
-    static const int env_hand = [] { const char *e = getenv("MPCX_QP_HANDOFF"); return e ? atoi(e) : 8; }();
-    const int hand = ctx->handoff_iters >= 0 ? ctx->handoff_iters : env_hand;
-    const bool hybrid = use_stage && hand > 0 && ctx->mpc.model != MPCX_MODEL_JERK5 && T <= 20 && B >= MPCX_STAGE_MIN_BATCH;
-    // the second phase either FOLLOWS the stage solver in the stream (helpers = 0) or runs beside it on `helpers` SIMDs of its own (side
-    // stream; not inside a stream capture: the records of a launch are told apart by a generation number a replayed graph would repeat)
-    static const int env_helpers = [] { const char *e = getenv("MPCX_QP_HELPERS"); return e ? atoi(e) : 0; }();
-    hipStreamCaptureStatus cap_h = hipStreamCaptureStatusNone;
-    const bool capturing = ctx->stream && hipStreamIsCapturing(ctx->stream, &cap_h) == hipSuccess && cap_h != hipStreamCaptureStatusNone;
-    const int helpers = (hybrid && env_helpers > 0 && ctx->side && !capturing) ? env_helpers : 0;
-    if (hybrid) {
-        int32_t rc = mpcx_ensure_order(ctx, (size_t)B);
-        if (rc != MPCX_OK) return rc;
-        if ((size_t)B > ctx->hand_cap) {
-            if (ctx->hand_rec) (void)hipFree(ctx->hand_rec);
-            if (ctx->hand_ready) (void)hipFree(ctx->hand_ready);
-            ctx->hand_rec = nullptr; ctx->hand_ready = nullptr; ctx->hand_cap = 0;
-            if (hipMalloc((void **)&ctx->hand_rec, (size_t)B * (18 * MPCX_T_MAX + 2) * sizeof(double)) != hipSuccess)
-                return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: cannot allocate the hand-over records of %d problems", B);
-            ctx->hand_cap = (size_t)B;
-        }
-        a.hand_mode = 1; a.hand_iters = hand; a.hand_cap = B;
-        a.hand_rec = ctx->hand_rec; a.hand_ctl = ctx->ticket + 1;
-        if (helpers) {
-            if (!ctx->hand_ready) {
-                if (hipMalloc((void **)&ctx->hand_ready, ctx->hand_cap * sizeof(int32_t)) != hipSuccess ||
-                    hipMemsetAsync(ctx->hand_ready, 0, ctx->hand_cap * sizeof(int32_t), ctx->stream) != hipSuccess)
-                    return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: cannot allocate the hand-over flags");
-                ctx->hand_gen = 0;
-            }
-            ctx->hand_gen++;
-            a.hand_live = 1; a.hand_gen = ctx->hand_gen; a.hand_grid = mpcx::qp_stage_grid(B, ctx->n_cu); a.hand_ready = ctx->hand_ready;
-        }
-    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (ctx->prof_qp && (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone)) {
@@ -930,31 +838,14 @@ extern "C" int32_t mpcx_qp_solve_batch(mpcx_ctx *ctx, int32_t B, const double *x
     }
     // stage-structured solver, eight lanes per problem (mpcx_qp_quad.hip) or the condensed solver of this file, one wavefront
     // per problem: mpcx_set_qp_solver / MPCX_QP_KERNEL=wave|stage choose; by default large batches and long horizons take the former
-    if (helpers && (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0) != hipSuccess))
-        return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: cannot fork the side stream");
     if (use_stage) mpcx::launch_qp_stage(a, ctx->stream, ctx->n_cu);
     else if (T <= 10) mpcx::launch_qp<10>(a, ctx->stream, grid);
     else if (T <= 13) mpcx::launch_qp<13>(a, ctx->stream, grid);
     else if (T <= 20) mpcx::launch_qp<20>(a, ctx->stream, grid);
     else mpcx::launch_qp<32>(a, ctx->stream, grid);
-    if (hybrid) {
-        // second phase: the records, one per wavefront of the condensed solver (every SIMD is free again).  What the 64-row LDL' cannot
-        // finish goes to the list below like any problem that solver gives up on.
-        mpcx::QpArgs h = a;
-        h.hand_mode = 2; h.order = nullptr; h.has_order = 0;
-        h.defer_fail = 1; h.fail_list = order_fail_list(ctx, (size_t)B); h.fail_count = ctx->ticket + 4;
-        hipStream_t hs = helpers ? ctx->side : ctx->stream;
-        const int hgrid = helpers ? helpers : grid;
-        if (T <= 10) mpcx::launch_qp<10>(h, hs, hgrid);
-        else if (T <= 13) mpcx::launch_qp<13>(h, hs, hgrid);
-        else mpcx::launch_qp<20>(h, hs, hgrid);
-        if (helpers && (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess))
-            return mpcx_fail(ctx, MPCX_E_LAUNCH, "qp_solve_batch: cannot join the side stream");
-        a.defer_fail = 1; a.fail_list = h.fail_list; a.fail_count = h.fail_count;      // (for the launch below)
-    }
-    if (!use_stage || hybrid) {
+    if (!use_stage) {
         mpcx::QpArgs f = a;
-        f.defer_fail = 0; f.hand_mode = 0;
+        f.defer_fail = 0;
         f.order = a.fail_list; f.has_order = 1;
         f.queue_len = a.fail_count; f.has_queue_len = 1;
         f.ticket = ctx->ticket + 5;                         // zeroed together with the counter

@@ -97,38 +97,6 @@ struct QueueSrc {
 #endif
     __device__ __forceinline__ int refill_min() const { return MPCX_REFILL_GROUPS * LQ; }   // in lanes
     __device__ __forceinline__ long max_rounds() const { return ((long)a.B + 2) * (long)(a.p.max_iter + 6) * (MPCX_POLISH_TRIES + 1); }
-    // ---- hybrid launch (QpArgs::hand_*): problems that have reached hand_iters iterations go to the condensed solver's wavefronts
-    __device__ __forceinline__ bool handoff_on() const { return a.hand_mode == 1; }
-    __device__ __forceinline__ int handoff_iters() const { return a.hand_iters; }
-    __device__ __forceinline__ int rec_stride() const { return 18 * a.p.T + 2; }
-    template <class Cx>
-    __device__ __forceinline__ int handoff_slot(Cx &cx, bool hand) const {      // the group's record slot (leader draws, group sum broadcasts)
-        int sl = 0;
-        if (hand && cx.q == 0) sl = atomicAdd(a.hand_ctl, 1) + 1;
-        sl = (int)cx.gsum((double)sl) - 1;
-        return (hand && sl < a.hand_cap) ? sl : -1;
-    }
-    __device__ __forceinline__ double *handoff_record(int slot) const { return a.hand_rec + (size_t)slot * rec_stride(); }
-    template <class Cx>
-    __device__ __forceinline__ void handoff_publish(Cx &cx, bool go, int slot, int pbi, int it, int loose_run, int ptested) const {
-        if (go && cx.q == 0) {
-            int32_t *meta = reinterpret_cast<int32_t *>(handoff_record(slot) + 18 * a.p.T);
-            meta[0] = pbi; meta[1] = it; meta[2] = loose_run; meta[3] = ptested;
-            a.status[pbi] = MPCX_QP_NUMERIC;          // until the receiver reports: a record nobody picks up reads as a failed solve
-            a.iters[pbi] = it;
-        }
-        if (a.hand_live) {
-            __threadfence();                              // the group's record is visible before its flag
-            if (go && cx.q == 0) __hip_atomic_store(a.hand_ready + slot, a.hand_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    template <class Cx>
-    __device__ __forceinline__ void finish(Cx &cx) const {                      // this wavefront writes no more records
-        if (a.hand_mode == 1 && a.hand_live) {
-            __threadfence();
-            if (cx.lane == 0) __hip_atomic_fetch_add(a.hand_ctl + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     template <class Cx>
     __device__ __forceinline__ bool fetch(Cx &cx, mpcx_mpc_params &P, int &pbi) const {
         int t = 0;

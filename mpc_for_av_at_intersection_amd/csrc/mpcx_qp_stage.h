@@ -494,33 +494,6 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
             if (running && !polish) { res_d = n_rd; res_p = n_rp; mu = n_mu; }
             const bool test = running && !trial && !polish && (pass == 0 || fresh);      // a group takes the exit tests once per iterate
             if (test && accepted) { status = MPCX_QP_OPTIMAL; running = false; }     // residuals of the accepted trial point: measured above, for the report
-            // hybrid launch (device policy only): an iterate that has reached the hand-over count leaves for a wavefront of the condensed
-            // solver, BEFORE its exit tests (the receiver takes them: loose_run and ptested travel as they were after the previous iterate)
-            if (src.handoff_on()) {
-                const bool hand = test && running && it >= src.handoff_iters();
-                if (cx.any(hand)) {
-                    const int slot = src.handoff_slot(cx, hand);                   // group-uniform; -1: no room (the problem stays)
-                    const bool go = hand && slot >= 0;
-                    double *rec = src.handoff_record(go ? slot : 0);
-                    MPCX_UNROLL
-                    for (int ls = 0; ls < SPL; ls++) {
-                        const int t = q * SPL + ls;
-                        if (go && act[ls]) {
-                            rec[t] = U0[ls]; rec[T + t] = U1[ls];
-                            MPCX_UNROLL
-                            for (int r = 0; r < ROWS; r++) {
-                                rec[2 * T + t * ROWS + r] = fabs(cx.ld_s(ls * ROWS + r));
-                                rec[2 * T + T * ROWS + t * ROWS + r] = cx.ld_l(ls * ROWS + r);
-                            }
-                        }
-                    }
-                    src.handoff_publish(cx, go, slot, pbi, it, loose_run, ptested);
-#ifdef MPCX_STAGE_PROFILE
-                    if (go) cx.lifetime(pbi, 1, 100 + (int)guard);
-#endif
-                    if (go) { running = false; have = false; }                     // nothing to hand in: the receiver writes the outputs
-                }
-            }
 #ifdef MPCX_STAGE_TRACE
             if (test) cx.trace(it, res_d, res_p, mu, trace_alpha, trace_aff, trace_sigma);
 #endif
@@ -1096,7 +1069,6 @@ MPCX_HD void solve_queue(Cx &cx, Src &src) {
         }
         cx.stamp(9);                    // [update]
     }
-    src.finish(cx);
 #undef PX
 #undef WXX
 #undef WYY

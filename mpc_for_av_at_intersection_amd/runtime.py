@@ -432,11 +432,6 @@ class Context:
         """'auto', 'condensed' (one wavefront per QP) or 'stage' (stage-structured solver, eight lanes per QP)"""
         self._chk(self.lib.mpcx_set_qp_solver(self._ctx, {'auto': 0, 'condensed': 1, 'stage': 2}[which]))
 
-    def set_qp_handoff(self, iterations: int):
-        """hybrid QP launch: iterations after which the stage solver hands a problem over to the condensed solver's wavefronts
-        (-1 = default, 0 = off); see mpcx_set_qp_handoff"""
-        self._chk(self.lib.mpcx_set_qp_handoff(self._ctx, int(iterations)))
-
     def set_linearisation_passes(self, passes: int):
         """lib/mpc.py MAX_ITER inside mpcx_closed_loop_run: (window, rollout, QP) passes per step (stock configuration: 1)"""
         self._chk(self.lib.mpcx_set_linearisation_passes(self._ctx, int(passes)))

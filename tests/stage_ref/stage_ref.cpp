@@ -49,12 +49,6 @@ struct HostSrc {            // a queue of exactly one problem
     mpcx_stage::Problem at(int) const { return pb; }
     long max_rounds() const { return (long)(p->max_iter + 6) * (MPCX_POLISH_TRIES + 1); }
     int refill_min() const { return 1; }
-    bool handoff_on() const { return false; }       // the hybrid launch is a device matter
-    int handoff_iters() const { return 0; }
-    template <class Cx> int handoff_slot(Cx &, bool) const { return -1; }
-    double *handoff_record(int) const { return nullptr; }
-    template <class Cx> void handoff_publish(Cx &, bool, int, int, int, int, int) const {}
-    template <class Cx> void finish(Cx &) const {}
     template <class Cx>
     bool fetch(Cx &, mpcx_mpc_params &, int &idx) { idx = 0; return taken++ == 0; }
 };
