@@ -416,7 +416,7 @@ def main():
             line['expand'] = {'nodes_per_s': nps, 'ms': ms, 'nodes': n_all, 'primitives': model.n_prim, 'half_plane_rows': model.n_rows,
                               'obstacles': model.n_obst, 'free_fraction': free_frac,
                               'algorithmic_bytes_per_node': bytes_node, 'hbm_GBps': nps * bytes_node / 1e9,
-                              'traffic': pmc_traffic_bytes('frontier:mpcx::expand_kernel') if world == 1 else None,
+                              'traffic': pmc_traffic_bytes('frontier:mpcx::expand_coop_kernel') if world == 1 else None,
                               'algorithmic_bytes_per_launch': bytes_node * n_all,
                               'hbm_frac': nps * bytes_node / 1e9 / (HBM_PEAK_GBS * world),
                               'fp64_fma_per_node_no_early_out': fma_node, 'fp64_equiv_frac_no_early_out': nps * fma_node * 2 / 1e12 / (FP64_PEAK_TFLOPS * world),

@@ -103,8 +103,14 @@ int32_t mpcx_qp_build_order(mpcx_ctx *ctx, int32_t B, hipStream_t st);   // coun
 #endif
 #ifndef MPCX_POLISH_MU
 #define MPCX_POLISH_MU 1e-5
+#endif
+#ifndef MPCX_POLISH_RP
 #define MPCX_POLISH_RP 1e-6
+#endif
+#ifndef MPCX_POLISH_RD
 #define MPCX_POLISH_RD 1e-3
+#endif
+#ifndef MPCX_POLISH_RHO
 #define MPCX_POLISH_RHO 1e8
 #define MPCX_POLISH_TRIES 3
 #define MPCX_POLISH_EPS_L 1e-9
