@@ -210,3 +210,43 @@ def test_arc_length_table_changes_nothing(ctx):
             for x, y in zip(outs[0], other):
                 assert np.array_equal(x, y)
         assert (outs[0][1] >= 0).any() and (outs[0][1] == -1).any()          # conflicts and free agents both occur
+
+
+@pytest.mark.parametrize('n_prim,n_obst,pts', [(5, 40, 20), (16, 70, 9), (1, 3, 40), (9, 24, 14)])
+def test_bulk_expansion_equals_per_lane_and_oracle_on_synthetic_models(ctx, n_prim, n_obst, pts):
+    """The bulk expansion kernel (>= 4096 nodes: pairs of a wavefront worked off together, record boxes from the template's box, obstacle boxes
+    four at a time by scalar loads) on models that exercise what the stock ones do not: other primitive counts (the node / primitive split of
+    a block), more than 32 obstacles (second chunk of the cull), templates of more than 32 points (second mask word), obstacles packed so
+    densely that a wavefront's pair queue overflows (per-lane fallback), boxes and octagons mixed.  Against the per-lane kernel of the small
+    launches and against the oracle, bit for bit (flags, successor poses, costs)."""
+    from oracle import oracle_py as orc
+    rng = np.random.default_rng(100 * n_prim + n_obst)
+    templates = [np.column_stack([rng.uniform(-1, 6, pts if k % 2 == 0 else max(1, pts // 3)), rng.uniform(-2, 2, pts if k % 2 == 0 else max(1, pts // 3))]) for k in range(n_prim)]
+    last = np.column_stack([rng.uniform(1, 6, n_prim), rng.uniform(-2, 2, n_prim), rng.uniform(-0.8, 0.8, n_prim)])
+    cost = rng.uniform(1, 6, n_prim)
+    hp, off = [], [0]
+    for o in range(n_obst):
+        cx, cy, hx, hy = rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(0.5, 9), rng.uniform(0.5, 9)
+        rows = [[1, 0, -(cx + hx)], [-1, 0, cx - hx], [0, 1, -(cy + hy)], [0, -1, cy - hy]]
+        if o % 3 == 0:          # an octagon: four diagonal rows behind the axis-aligned ones (obstacles.py:140-148 order)
+            r = 1.2 * max(hx, hy)
+            rows += [[a, b, -(a * cx + b * cy + r)] for a, b in ((0.7071, 0.7071), (-0.7071, 0.7071), (0.7071, -0.7071), (-0.7071, -0.7071))]
+        hp += rows; off.append(len(hp))
+    hp, off = np.array(hp, dtype=np.float64), np.array(off, dtype=np.int32)
+    model = ctx.search_model(templates, last, cost, hp, off)
+    om = orc.SearchModel(templates, last, cost, hp, off)
+    n = 9000
+    nodes = np.column_stack([rng.uniform(-35, 35, n), rng.uniform(-35, 35, n), rng.uniform(-np.pi, np.pi, n)])
+    nodes[7] = [0.0, 0.0, 0.3]                      # linalg.py:13-17: rotation only
+    dev = ctx.f64(nodes)
+    cs = ctx.f64(np.column_stack([np.cos(nodes[:, 2]), np.sin(nodes[:, 2])]))
+    bulk = ctx.expand(model, dev, nodes_cs=cs)
+    ctx.synchronize()
+    col, nbr, cst = bulk['collide'].cpu().numpy(), bulk['nbr'].cpu().numpy(), bulk['cost'].cpu().numpy()
+    for lo in (0, 3000, 6000):
+        part = ctx.expand(model, dev[lo:lo + 3000].contiguous(), nodes_cs=cs[lo:lo + 3000].contiguous())
+        assert np.array_equal(part['collide'].cpu().numpy(), col[lo:lo + 3000])
+        assert np.array_equal(part['nbr'].cpu().numpy(), nbr[lo:lo + 3000]) and np.array_equal(part['cost'].cpu().numpy(), cst[lo:lo + 3000])
+    onbr, ocol = orc.expand(om, nodes, host_trig=True)
+    assert np.array_equal(ocol, col) and np.array_equal(onbr, nbr)
+    assert 0.02 < col.mean() < 0.98
