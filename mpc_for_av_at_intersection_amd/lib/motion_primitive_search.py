@@ -57,6 +57,7 @@ class MotionPrimitiveSearch:
         # device tables: primitive ids follow the dict's iteration order (the order neighbour_function yields in)
         self._ctx = ctx if ctx is not None else context()
         self._names = list(mps.keys())
+        self._mps_key = hash(tuple((n, np.ascontiguousarray(mps[n].points, dtype=np.float64).tobytes()) for n in self._names))   # same primitives, same key
         hp_off = np.cumsum([0] + [len(h) for h in self._obstacles_hp]).astype(np.int32)
         hp = np.concatenate(self._obstacles_hp, axis=0) if self._obstacles_hp else np.zeros((0, 3))
         self._model = self._ctx.search_model([self._mp_collision_points[n] for n in self._names],
@@ -116,7 +117,7 @@ class MotionPrimitiveSearch:
         the device's values against): the squares through Python's `**`, the rest is IEEE arithmetic numpy evaluates identically"""
         gx, gy, gth = self._goal_point
         ex, ey = nodes[:, 0] - gx, nodes[:, 1] - gy
-        sq = np.array([v ** 2 for v in ex.tolist()]) + np.array([v ** 2 for v in ey.tolist()])
+        sq = _py_square(ex) + _py_square(ey)
         ad = np.abs(nodes[:, 2] - gth)
         return np.sqrt(sq) + 2.7 * np.minimum(ad, ad - self._allowed_goal_theta_difference / 2)
 
@@ -288,6 +289,47 @@ def plan_many(searches: List[MotionPrimitiveSearch], debug=False):
 
 # ------------------------------------------------------------------ device-resident searches (csrc/mpcx_astar.hip)
 _CLOSURES = {}
+_DEVICE_TABLES = {}
+
+
+def _py_square(x: np.ndarray) -> np.ndarray:
+    """x ** 2 as Python floats compute it (libm pow: NOT always the correctly rounded x * x), for an array.  numpy.float_power goes
+    through the same pow; the first elements are checked against the interpreter every time, and should the two ever part (another
+    numpy, another libm) the element-by-element loop takes over."""
+    out = np.float_power(x, 2)
+    k = min(len(x), 64)
+    if k and not np.array_equal(out[:k], np.array([v ** 2 for v in x[:k].tolist()])):
+        return np.array([v ** 2 for v in x.tolist()])
+    return out
+
+
+def paths_to_full_trajectories(searches: List['MotionPrimitiveSearch'], paths: List[List[NodeType]]) -> List[np.ndarray]:
+    """`path_to_full_trajectory` of many searches that share their primitives, all edges in ONE transform launch and one copy back"""
+    if not searches:
+        return []
+    s0 = searches[0]
+    ctx = s0._ctx
+    names0 = list(s0._mps)
+    offs, cur = {}, 0
+    for nme in names0:
+        offs[nme] = cur
+        cur += len(s0._mps[nme].points)
+    edges_off, edges_cnt, edge_nodes, spans = [], [], [], []
+    for s, path in zip(searches, paths):
+        first = len(edges_off)
+        for a, b in zip(path[:-1], path[1:]):
+            nme = s._points_to_mp_names[a, b]
+            edges_off.append(offs[nme]); edges_cnt.append(len(s0._mps[nme].points)); edge_nodes.append(a)
+        spans.append((first, len(edges_off)))
+    if not edges_off:
+        return [np.zeros((0, 3)) for _ in searches]
+    pts = ctx.f64(np.concatenate([s0._mps[nme].points for nme in names0], axis=0))
+    cnts = np.array(edges_cnt)
+    out = ctx.transform(ctx.f64(np.array(edge_nodes, dtype=np.float64)), ctx.i32(np.array(edges_off)), ctx.i32(cnts), pts, int(cnts.max())).cpu().numpy()
+    res = []
+    for a, b in spans:
+        res.append(np.concatenate([out[i, :cnts[i] - 1] for i in range(a, b)], axis=0) if b > a else np.zeros((0, 3)))
+    return res
 
 
 def heading_closure(start_thetas, dthetas, depth: int) -> np.ndarray:
@@ -347,8 +389,14 @@ def plan_many_device(searches: List['MotionPrimitiveSearch'], max_expansions: in
         if not todo:
             break
         if cs_t is None:
-            cs_t = ctx.f64(theta_tab)
-            cs_v = ctx.f64(np.column_stack([np.cos(theta_tab), np.sin(theta_tab)]))
+            # the table on the device, kept per context and closure (2.1 M headings = 50 MB for the stock start poses: cos / sin and the
+            # upload cost more than the searches)
+            tkey = (id(ctx), theta_tab.size, float(theta_tab[0]), float(theta_tab[-1]), float(theta_tab.sum()))
+            if tkey not in _DEVICE_TABLES:
+                if len(_DEVICE_TABLES) > 8:
+                    _DEVICE_TABLES.clear()
+                _DEVICE_TABLES[tkey] = (ctx.f64(theta_tab), ctx.f64(np.column_stack([np.cos(theta_tab), np.sin(theta_tab)])))
+            cs_t, cs_v = _DEVICE_TABLES[tkey]
         hov_n = hov_h = None
         if overrides:
             keys = sorted(overrides)
@@ -361,10 +409,13 @@ def plan_many_device(searches: List['MotionPrimitiveSearch'], max_expansions: in
         info['launches'] += 1
         status = out['status'].cpu().numpy(); n_exp = out['n_exp'].cpu().numpy(); n_push = out['n_push'].cpu().numpy()
         path_len = out['path_len'].cpu().numpy(); costs = out['cost'].cpu().numpy(); misses = out['miss'].cpu().numpy()
-        # the pushes of all searches in one copy (variable-length rows)
-        push_rows = [out['push_log'][j, :int(n_push[j])] for j in range(len(todo))]
-        push_all = torch.cat(push_rows).cpu().numpy() if push_rows else np.zeros((0, 4))
+        # the pushes of all searches in one gather and one copy (variable-length rows), paths and primitive ids likewise
+        pl_t = out['push_log']
+        keep = torch.arange(pl_t.shape[1], device=pl_t.device)[None, :] < out['n_push'][:, None].to(torch.int64)
+        push_all = pl_t[keep].cpu().numpy()
         push_off = np.concatenate([[0], np.cumsum(n_push)]).astype(np.int64)
+        pmax = int(path_len.max()) if len(path_len) else 0
+        path_all = out['path'][:, :pmax].cpu().numpy(); prim_all = out['path_prim'][:, :pmax].cpu().numpy()
         again, new_thetas = [], []
         for j, i in enumerate(todo):
             s = searches[i]
@@ -392,8 +443,8 @@ def plan_many_device(searches: List['MotionPrimitiveSearch'], max_expansions: in
             if status[j] == _lib.ASTAR_EXHAUSTED:
                 raise Exception("No solution found.")
             n = int(path_len[j])
-            nodes = out['path'][j, :n].cpu().numpy()[::-1]
-            prims = out['path_prim'][j, :n].cpu().numpy()[::-1]
+            nodes = path_all[j, :n][::-1]
+            prims = prim_all[j, :n][::-1]
             path = [tuple(float(v) for v in p) for p in nodes]
             for a, b, k in zip(path[:-1], path[1:], prims[1:]):
                 s._points_to_mp_names[a, b] = s._names[int(k)]
@@ -410,4 +461,11 @@ def plan_many_device(searches: List['MotionPrimitiveSearch'], max_expansions: in
         todo = again
     if todo:
         raise RuntimeError('plan_many_device: %d searches did not settle in %d rounds' % (len(todo), max_rounds))
-    return [(c, p, s.path_to_full_trajectory(p)) for s, (c, p) in zip(searches, results)], info
+    trajs = [None] * len(searches)
+    groups = {}
+    for i, s in enumerate(searches):        # one transform launch per set of primitives
+        groups.setdefault(s._mps_key, []).append(i)
+    for idx in groups.values():
+        for i, t in zip(idx, paths_to_full_trajectories([searches[i] for i in idx], [results[i][1] for i in idx])):
+            trajs[i] = t
+    return [(c, p, t) for (c, p), t in zip(results, trajs)], info
