@@ -112,6 +112,9 @@ __device__ __forceinline__ double grp8_max(double v) {
 __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)[4], int na, const double *pred,
                               int ooff, int nobs, int oskip, const double *rem, const double *rcs, int n,
                               double (*s_box)[4], unsigned short *s_queue, int lane, double &hx, double &hy) {
+#ifdef MPCX_INTER_PROFILE
+    int dbg_queued = 0;      // dev build: candidates that reached a run's queue (returned in hx when there is no conflict)
+#endif
     const double md = 2.0 * ip.radius;
     const double md2lo = md * md * (1.0 - 1e-12), md2hi = md * md * (1.0 + 1e-12);
     const int steps = ip.pred_steps, w = ip.frame_window;
@@ -170,6 +173,9 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
                 qn += __popcll(m);
             }
             if (qn == 0) continue;
+#ifdef MPCX_INTER_PROFILE
+            dbg_queued += qn;
+#endif
             __syncthreads();
             const int f0 = sg * SL, f1 = (sg + 1) * SL < F ? (sg + 1) * SL : F;
             bool found = false;
@@ -208,6 +214,9 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
         }
     }
     best = wave_min_ll(best);
+#ifdef MPCX_INTER_PROFILE
+    if (best == NOKEY) hx = (double)dbg_queued;
+#endif
     if (best == NOKEY) return -1;
     // decode the obstacle disc of the first row
     const int co = (int)(best & 1);
@@ -522,7 +531,11 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, s_queue, lane, hx, hy);
     ISTAMP(5);      // conflict search (+ path scan on a hit)
     if (first < 0) {
+#ifdef MPCX_INTER_PROFILE
+        if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; file_key(len); a.hit_xy[2 * p] = hx; a.hit_xy[2 * p + 1] = 0; }
+#else
         if (lane == 0) { a.hit_idx[p] = -1; a.cut_len[p] = len; file_key(len); a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
+#endif
         return;
     }
     // ---- collision_avoidance.py:107-119 on trajectory_full, then mpc_intersection.py:130-134

@@ -21,3 +21,8 @@ for n, v in zip(names, prof): print('  %-30s %5.1f %%  %8.0f cycles per ego' % (
 print('  total %.0f cycles per ego' % (prof.sum() / P))
 
 print('  per-ego total: median %.0f  p90 %.0f  max %.0f cycles' % (np.median(per.sum(1)), np.quantile(per.sum(1), 0.9), per.sum(1).max()))
+
+hi = sim.inter['hit_idx'][:P].cpu().numpy(); hq = big[:P, 0].cpu().numpy()
+free = hi == -1
+print('  egos without a conflict: %.1f %%; of those, no candidate in any run box: %.1f %%; candidates queued (mean over conflict-free egos): %.1f'
+      % (100 * free.mean(), 100 * (hq[free] == 0).mean(), hq[free].mean()))
