@@ -13,6 +13,7 @@
 // reach, and the FIRST ROW IN THE REFERENCE'S ORDER is recovered as the minimum of an integer key over all hits
 // (bit-exact index outputs).
 #include "mpcx_common.h"
+#include <type_traits>
 
 namespace mpcx {
 
@@ -109,6 +110,17 @@ __device__ __forceinline__ double grp8_max(double v) {
     v = fmax(v, dpp_mov<0xB1>(v, v)); v = fmax(v, dpp_mov<0x4E>(v, v)); v = fmax(v, dpp_mov<0x141>(v, v));
     return v;
 }
+// j / d and j % d for 0 <= j < 2^20, 1 <= d <= MPCX_PRED_STEPS_MAX through the single-precision reciprocal (+ one correction either way):
+// the integer division the compiler emits costs ~25 instructions, and the candidate decode below runs it sixteen times per lane in a
+// kernel that is bound by instruction issue
+__device__ __forceinline__ void divmod_small(int j, int d, float inv_d, int &quo, int &rem) {
+    int q = (int)(((float)j + 0.5f) * inv_d);
+    int r = j - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    if (r >= d) { q += 1; r -= d; }
+    quo = q; rem = r;
+}
+
 __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)[4], int na, const double *pred,
                               int ooff, int nobs, int oskip, const double *rem, const double *rcs, int n,
                               double (*s_box)[4], unsigned short *s_queue, int lane, double &hx, double &hy) {
@@ -118,6 +130,7 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
     const double md = 2.0 * ip.radius;
     const double md2lo = md * md * (1.0 - 1e-12), md2hi = md * md * (1.0 + 1e-12);
     const int steps = ip.pred_steps, w = ip.frame_window;
+    const float inv_steps = 1.0f / (float)steps;
     const double slack = md * (1.0 + 1e-9) + 1e-9;      // conservative: never culls a pair within md
 
     // ---- boxes of NSEG runs of ego frames, inflated by slack > md so that no pair within md is ever skipped.
@@ -153,7 +166,9 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
         for (int u = 0; u < 8; u++) {
             const int cidx = cb + u * WAVE + lane;
             const int cc = cidx < ncand_all ? cidx : ncand_all - 1;
-            const int co = cc & 1, g = (cc >> 1) % steps, o = (cc >> 1) / steps;   // o: local obstacle rank
+            const int co = cc & 1;
+            int g, o;                                                              // o: local obstacle rank
+            divmod_small(cc >> 1, steps, inv_steps, o, g);
             int pool = ooff + o;
             if (oskip >= 0 && pool >= oskip) pool += 1;                                    // skip self
             const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
@@ -183,7 +198,9 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
                 const int it = it0 + lane;
                 if (it < qn) {
                     const int cidx = cb + (int)s_queue[it];
-                    const int co = cidx & 1, g = (cidx >> 1) % steps, o = (cidx >> 1) / steps;
+                    const int co = cidx & 1;
+                    int g, o;
+                    divmod_small(cidx >> 1, steps, inv_steps, o, g);
                     int pool = ooff + o;
                     if (oskip >= 0 && pool >= oskip) pool += 1;
                     const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
@@ -449,15 +466,18 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     const double cum0 = tab ? cumtab[tidx] : 0.0;
     const double inv_const = frcp(dl_const);
     const double marg = tab ? ip.path_cum_err + 1e-13 : 1.01e-10;     // how far the fast running sum can be from np.cumsum's
-    auto resample = [&](bool check, bool &unsure) -> int {
+    auto resample = [&](auto check_tag, bool &unsure) -> int {
+        constexpr bool check = decltype(check_tag)::value;      // two instantiations: the fast pass carries no division and no 64-bit integers
         // check = true: the fast pass -- running sums from the table (or the parallel scan), quotient by reciprocal (<= 2 ulp from the
         // division), bucket accepted only outside the margin; check = false: np.cumsum's own sums (prefix_exact) and the division
         int base = 0;
         long long q_carry = 0;                // bucket of the last element of the previous 64-block
+        double qd_carry = 0.0;                // (fast pass: the buckets as doubles -- floor() of a quotient below 2^52 is an exact integer)
         unsure = false;
         for (int i0 = 0; i0 < n; i0 += WAVE) {
             const int i = i0 + lane;
             long long q = 0;
+            double qd = 0.0;
             if (i < n) {
                 double dl = dl_const, inv = inv_const;
                 // the predicted speed v + a (i + 1) is monotone in i: once the FIRST point of a 64-point block has reached max_speed every
@@ -468,17 +488,28 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
                     if (check) inv = frcp(dl);
                 }
                 const double c = s_cum[shift + i];
-                const double r = check ? c * inv : __ddiv_rn(c, dl);
-                q = (long long)floor(r);
-                if (check && c != 0.0) {          // c == 0 is exact in every summation order
-                    const double room = fabs(r - rint(r));
-                    if (!(dl > 0.0) || !(room > marg * inv + 2e-15 * fabs(r))) unsure = true;
-                }
+                if constexpr (check) {
+                    const double r = c * inv;
+                    qd = floor(r);
+                    if (c != 0.0) {               // c == 0 is exact in every summation order
+                        const double room = fabs(r - rint(r));
+                        if (!(dl > 0.0) || !(r < 4e15) || !(room > marg * inv + 2e-15 * fabs(r))) unsure = true;
+                    }
+                } else
+                    q = (long long)floor(__ddiv_rn(c, dl));
             }
-            long long qprev = __shfl_up(q, 1, WAVE);
-            if (lane == 0) qprev = q_carry;
-            q_carry = __shfl(q, WAVE - 1, WAVE);
-            const bool keep = (i < n) && ((i == 0) || (i == n - 1) || (q - qprev >= 1));
+            bool adv;
+            if constexpr (check) {
+                const double qprev = lane_prev(qd, qd_carry);       // wave_shr:1, lane 0 takes the previous block's last bucket
+                qd_carry = rdlane(qd, WAVE - 1);
+                adv = qd - qprev >= 1.0;
+            } else {
+                long long qprev = __shfl_up(q, 1, WAVE);
+                if (lane == 0) qprev = q_carry;
+                q_carry = __shfl(q, WAVE - 1, WAVE);
+                adv = q - qprev >= 1;
+            }
+            const bool keep = (i < n) && ((i == 0) || (i == n - 1) || adv);
             const unsigned long long m = __ballot(keep);
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
             if (keep && pos < MAXF) s_keep[pos] = i;
@@ -498,14 +529,14 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     __syncthreads();
     ISTAMP(2);      // cumulative lengths
     bool unsure;
-    int na = resample(true, unsure);
+    int na = resample(std::true_type{}, unsure);
 #ifdef MPCX_INTER_FORCE_EXACT
     unsure = true;                            // dev build: every ego takes the sequential path (tests run both builds)
 #endif
     if (__ballot(unsure)) {
         __syncthreads();
         prefix_exact();
-        na = resample(false, unsure);
+        na = resample(std::false_type{}, unsure);
     }
     if (na > MAXF) {
         if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; file_key(len); a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
