@@ -34,6 +34,7 @@ struct mpcx_ctx {
     const int32_t *bin_hint = nullptr;    // set around the conflict search: iteration counts of the previous step (queue key)
     bool bin_scatter = false;             // set around the window selection: write `order`
     bool bin_reset = false;               // set around the plant step: zero bins and ticket
+    const double *pack_state = nullptr, *pack_applied = nullptr;   // mpcx_closed_loop_run, local pool: the prediction kernel packs the pool rows itself
     int32_t *inter_prev_save = nullptr;   // mpcx_closed_loop_run: where the conflict search leaves the cut lengths it read (the queue order's `moved` test)
     hipStream_t side = nullptr; // side stream of mpcx_mpc_prepare_batch: the warm-start rollout runs beside the window selection (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

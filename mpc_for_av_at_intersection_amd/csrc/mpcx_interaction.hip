@@ -22,15 +22,27 @@ struct PredArgs {
     int n;
     const double *obs6;
     double *pred;    // [n][steps][2][2]
+    // closed loop, local pool: the pool row of agent o is packed here from its state and applied inputs (MovingObstacle*.get():
+    // x, y, v, yaw, a, steer) instead of by a launch of its own; nullptr: obs6 is read as it is
+    const double *pack_state, *pack_applied;
+    double *pack_out;
 };
 
 // moving_obstacles_prediction.py:21-28: v is updated BEFORE yaw; disc centres as trajectories.py:11-37
 __global__ __launch_bounds__(256) void predict_kernel(PredArgs a) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= a.n) return;
-    const double *s6 = a.obs6 + 6 * (size_t)o;
-    double x = s6[0], y = s6[1], v = s6[2], yaw = s6[3];
-    const double acc = s6[4], tn = tan(s6[5]);
+    double x, y, v, yaw, acc, steer;
+    if (a.pack_state) {
+        const double *st = a.pack_state + 4 * (size_t)o;
+        x = st[0]; y = st[1]; v = st[2]; yaw = st[3]; acc = a.pack_applied[2 * o + 1]; steer = a.pack_applied[2 * o];
+        double *row = a.pack_out + 6 * (size_t)o;
+        row[0] = x; row[1] = y; row[2] = v; row[3] = yaw; row[4] = acc; row[5] = steer;
+    } else {
+        const double *s6 = a.obs6 + 6 * (size_t)o;
+        x = s6[0]; y = s6[1]; v = s6[2]; yaw = s6[3]; acc = s6[4]; steer = s6[5];
+    }
+    const double tn = tan(steer);
     const double dt = a.ip.dt;
     double s, c;
     sincos(yaw, &s, &c);
@@ -665,7 +677,7 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
     if (P == 0) return MPCX_OK;
     { int32_t rc = mpcx_ensure_pred(ctx, (size_t)(n_obs_pool > 0 ? n_obs_pool : 1) * ip->pred_steps * 4); if (rc != MPCX_OK) return rc; }
     if (n_obs_pool > 0) {
-        mpcx::PredArgs pa{*ip, n_obs_pool, obs6, ctx->pred};
+        mpcx::PredArgs pa{*ip, n_obs_pool, obs6, ctx->pred, ctx->pack_state, ctx->pack_applied, ctx->pack_state ? const_cast<double *>(obs6) : nullptr};
         hipLaunchKernelGGL(mpcx::predict_kernel, dim3((n_obs_pool + 63) / 64), dim3(64), 0, ctx->stream, pa);
     }
     // capacity: max_path_len path points (0 = MPCX_MAX_REMAINING; never below 512), rounded up to whole wavefronts; the LDS that

@@ -45,8 +45,8 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
         if (rc != MPCX_OK) return rc;
         pool_rows = P * ctx->comm_world;
     } else {
-        mpcx::PackArgs pa{P, c->state, c->applied, c->obs6};
-        hipLaunchKernelGGL(mpcx::pack_pool_kernel, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, pa);
+        // local pool: row q is agent q, and the prediction kernel (inside mpcx_interaction_batch) packs it on its way -- no launch of its own
+        ctx->pack_state = c->state; ctx->pack_applied = c->applied;
     }
     // the conflict search leaves the cut lengths of the previous step in ctx->prev_cut (the queue of the QP kernel puts the agents whose
     // cut moved at the front) and files every agent under its work-queue key (previous iteration count + "the cut moved"): hard problems first.  The window
@@ -59,6 +59,7 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
                                 c->obs_off, c->obs_cnt, c->obs_skip, c->traj_idx, c->hit_idx, c->hit_xy, c->cut_len);
     ctx->inter_prev_save = nullptr;
     ctx->bin_hint = nullptr;
+    ctx->pack_state = nullptr; ctx->pack_applied = nullptr;
     if (rc != MPCX_OK) return rc;
     // lib/mpc.py:226-237: MAX_ITER passes of (reference window, rollout, QP); from the second pass on the window is spaced by the
     // previous pass's speeds (row 2 of its x) and the rollout uses its inputs.  (Where a pass fails the reference crashes in the next
