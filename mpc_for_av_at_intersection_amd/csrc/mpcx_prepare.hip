@@ -224,7 +224,7 @@ extern "C" int32_t mpcx_mpc_prepare_batch_ov(mpcx_ctx *ctx, int32_t B, const dou
         if (rc != MPCX_OK) return rc;
     }
     hipLaunchKernelGGL(mpcx::ref_window_kernel, dim3((B + mpcx::PREP_WAVES - 1) / mpcx::PREP_WAVES), dim3(64 * mpcx::PREP_WAVES), 0, ctx->stream, ra);
-    if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess)
+    if (hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot join the side stream");
     return mpcx_check_launch(ctx, "prepare kernels");
 }
@@ -236,6 +236,10 @@ int32_t mpcx_rollout_fork(mpcx_ctx *ctx, int32_t B, const double *state, const d
     if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot fork the side stream");
     hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->side, ro);
+    // the join event right behind the rollout: by the time the context's stream waits for it (in front of the solve) the marker has long
+    // been processed -- recorded there, the wait paid for the side queue's marker AND its own barrier
+    if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot record the join event");
     return MPCX_OK;
 }
 
