@@ -289,7 +289,6 @@ def plan_many(searches: List[MotionPrimitiveSearch], debug=False):
 
 # ------------------------------------------------------------------ device-resident searches (csrc/mpcx_astar.hip)
 _CLOSURES = {}
-_DEVICE_TABLES = {}
 
 
 def _py_square(x: np.ndarray) -> np.ndarray:
@@ -351,6 +350,8 @@ def heading_closure(start_thetas, dthetas, depth: int) -> np.ndarray:
         if frontier.size == 0:
             break
         seen = np.union1d(seen, frontier)
+    if len(_CLOSURES) > 8:
+        _CLOSURES.clear()
     _CLOSURES[key] = seen
     return seen
 
@@ -391,12 +392,13 @@ def plan_many_device(searches: List['MotionPrimitiveSearch'], max_expansions: in
         if cs_t is None:
             # the table on the device, kept per context and closure (2.1 M headings = 50 MB for the stock start poses: cos / sin and the
             # upload cost more than the searches)
-            tkey = (id(ctx), theta_tab.size, float(theta_tab[0]), float(theta_tab[-1]), float(theta_tab.sum()))
-            if tkey not in _DEVICE_TABLES:
-                if len(_DEVICE_TABLES) > 8:
-                    _DEVICE_TABLES.clear()
-                _DEVICE_TABLES[tkey] = (ctx.f64(theta_tab), ctx.f64(np.column_stack([np.cos(theta_tab), np.sin(theta_tab)])))
-            cs_t, cs_v = _DEVICE_TABLES[tkey]
+            tkey = (theta_tab.size, float(theta_tab[0]), float(theta_tab[-1]), float(theta_tab.sum()))
+            tabs = ctx.__dict__.setdefault('_astar_heading_tables', {})      # the tensors live and die with their context
+            if tkey not in tabs:
+                if len(tabs) > 4:
+                    tabs.clear()
+                tabs[tkey] = (ctx.f64(theta_tab), ctx.f64(np.column_stack([np.cos(theta_tab), np.sin(theta_tab)])))
+            cs_t, cs_v = tabs[tkey]
         hov_n = hov_h = None
         if overrides:
             keys = sorted(overrides)
