@@ -258,3 +258,23 @@ def test_world_tables_reproduce_reference_half_planes():
     assert f.obstacles == [] and f.goal_point[2] == 0 and abs(f.goal_point[0] - (1.0 + 10 * np.cos(0.3))) < 1e-15
     with pytest.raises(KeyError):
         sc.t_intersection(turn_indicator=4, start_pos=4)        # the reference raises KeyError for this combination too
+
+
+def test_arc_length_table_error_bound_holds():
+    """runtime.path_tables: a difference of two table entries is within the stated bound of the reference's own running sum over the same
+    steps (np.cumsum restarted at the first of the two points, trajectories.py:72-79) -- the premise of the conflict search's fast pass"""
+    from mpc_for_av_at_intersection_amd.runtime import path_tables
+    rng = np.random.default_rng(3)
+    routes = [np.cumsum(rng.uniform(0.01, 0.4, (n, 3)), axis=0) * rng.uniform(0.5, 3.0) for n in (720, 37, 2, 1500)]
+    table = np.concatenate(routes)
+    offs = np.cumsum([0] + [len(r) for r in routes])
+    cum, err = path_tables(table, offs)
+    assert 0 < err < 1e-9
+    worst = 0.0
+    for a, b in zip(offs[:-1], offs[1:]):
+        assert cum[a] == 0.0 and (np.diff(cum[a:b]) >= 0).all()
+        for start in rng.integers(a, b, 12):
+            pts = table[start:b, :2]
+            steps = np.append(0.0, np.linalg.norm(pts[1:] - pts[:-1], axis=1))
+            worst = max(worst, np.abs((cum[start:b] - cum[start]) - steps.cumsum()).max())
+    assert worst <= err, (worst, err)
