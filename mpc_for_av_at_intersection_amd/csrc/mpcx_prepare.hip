@@ -223,8 +223,13 @@ extern "C" int32_t mpcx_mpc_prepare_batch_ov(mpcx_ctx *ctx, int32_t B, const dou
         int32_t rc = mpcx_rollout_fork(ctx, B, state, u_warm, xbar);
         if (rc != MPCX_OK) return rc;
     }
+    // a rollout forked long ago (mpcx_closed_loop_run: at the start of the step) is joined IN FRONT of the window selection: the queue
+    // works the barrier off while the conflict search is still running, and nothing stands between the window kernel and the solve;
+    // a rollout forked just now runs beside the window selection and is joined behind it
+    if (forked && hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess)
+        return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot join the side stream");
     hipLaunchKernelGGL(mpcx::ref_window_kernel, dim3((B + mpcx::PREP_WAVES - 1) / mpcx::PREP_WAVES), dim3(64 * mpcx::PREP_WAVES), 0, ctx->stream, ra);
-    if (hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess)
+    if (!forked && hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot join the side stream");
     return mpcx_check_launch(ctx, "prepare kernels");
 }
