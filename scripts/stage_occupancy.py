@@ -39,5 +39,9 @@ for step in range(4):
         m = (key >= lo) & (key <= hi)
         if m.any():
             print('   key %2d..%2d: %5d problems, constrained %5d; start rounds %s' % (lo, hi, m.sum(), (m & c).sum(), np.bincount(start[m], minlength=12)[:13].tolist()))
+    light = alive & (spec == occ)
+    lastw = np.argmax(last)      # a wavefront that ran the longest
+    print('   wavefront-rounds in which every working group is in a trial / polish round: %.1f %% of the live ones; per round: %s; in the longest-running wavefront: %d of %d'
+          % (100.0 * light.sum() / alive.sum(), ' '.join('%d' % v for v in light.sum(0)[:last.max()]), int(light[lastw].sum()), int(last[lastw])))
     busy = occ[alive]
     print('   mean groups at work in a live wavefront-round: %.2f of 8' % busy.mean())
