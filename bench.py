@@ -12,6 +12,9 @@ value = 4096 * steps / max-over-ranks time.  Extra keys of the same JSON line (e
   expand         motion-primitive expansion of a 2^20-node Prius frontier, HIP-event timed
   agent_sharded  (N > 1) the layout with a real exchange step: agents sharded over ranks, one RCCL all-gather per step
   weak           (N > 1) every rank runs the full 4096-instance batch
+  config2        (N = 1) SURVEY 8(d) config 2 / BASELINE configs[1]: 256 independent perturbed-state instances (batch.config2_batch)
+  free_flow      (N = 1) the same generator at 32 768 instances: a launch of 32 768 QPs none of which stands in a queue at the junction
+  shard_proxy    (N = 1) the per-rank shares of the headline batch at N = 2 / 4 / 8 (2048 / 1024 / 512 instances) timed on this GPU
   cpu_baseline   the oracle on this host: one thread, and all cores (threads over agents in C)
 
     python bench.py --gpus 1 --steps 20 --warmup 5
@@ -194,7 +197,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from mpc_for_av_at_intersection_amd.batch import prius_frontier, stock_routes, synthetic_batch
+    from mpc_for_av_at_intersection_amd.batch import ALL_STOCK_PAIRS, config2_batch, prius_frontier, stock_routes, synthetic_batch
     from mpc_for_av_at_intersection_amd.runtime import Context, MpcParams
     from mpc_for_av_at_intersection_amd import sharding
     ctx = Context(local)
@@ -349,6 +352,54 @@ def main():
             line['steady_state_value'] = line['steady_state']['value']
         except Exception as e:                       # an extra must never take the headline line down
             line['steady_state'] = {'error': repr(e)}
+        # -------------------------------------------------------------- SURVEY 8(d) config 2 (BASELINE configs[1]) and the same generator at 32 768 QPs
+        try:
+            if world == 1:
+                routes12, dl12, cd12 = stock_routes(ctx, ALL_STOCK_PAIRS)
+
+                def perturbed(Bc):
+                    s2 = config2_batch(ctx, B=Bc, T=T, seed=0, routes=routes12, dl=dl12, cd=cd12, burn_in=args.burn_in)
+                    s2.run(args.warmup)
+                    el2, it2, fl2, ms2, _ = timed(s2, args.steps)
+                    s2.check()
+                    k2 = it2 / (Bc * args.steps)
+                    tf2 = float(((s2.sol['iters'] == 0) & (s2.sol['status'] == 0)).double().mean().item())
+                    f2 = qp_flops_condensed(T, k2)
+                    return {'instances': Bc, 'agents': 1, 'horizon': T, 'value': Bc * args.steps / el2, 'unit': 'MPC timesteps/s (= agent-QPs/s: one agent per instance)',
+                            'ms_per_step': 1e3 * el2 / args.steps, 'kernel_ms': ms2, 'mean_ipm_iters': k2, 'max_ipm_iters': timed.max_iterations,
+                            'qp_solved_by_trial_pass': tf2, 'qp_failures': int(fl2),
+                            'frac_survey_formula': f2 * Bc / (ms2 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                            'mean_speed_at_end': float(s2.state[:, 2].mean().item())}
+                line['config2'] = perturbed(256)
+                line['config2']['note'] = ('SURVEY 8(d) config 2 = BASELINE configs[1]: 256 INDEPENDENT single-ego instances, route uniform over the 12 stock A* paths, arc '
+                                           'position uniform, lateral offset N(0, 0.3 m), heading error N(0, 0.05 rad), v ~ U[0, 8.33 m/s] (seed 0), %d burn-in + %d warm-up steps, '
+                                           'then %d timed closed-loop steps; condensed solver qp_kernel<%d> (one wavefront per QP)' % (args.burn_in, args.warmup, args.steps, T))
+                line['free_flow'] = perturbed(32768)
+                line['free_flow']['note'] = ('NOT the metric\'s configuration: config 2\'s generator at 32 768 instances -- a QP launch of the headline\'s size in which nobody '
+                                             'queues at the junction (no other agents): most QPs are constrained (acceleration bound when slow, steering-rate bound in turns). '
+                                             'frac_survey_formula = SURVEY 8(d) F_qp(T, measured mean iterations) x QPs / kernel time / 78.6 TFLOP/s')
+        except Exception as e:
+            line.setdefault('config2', {'error': repr(e)}); line.setdefault('free_flow', {'error': repr(e)})
+        # -------------------------------------------------------------- the 8-GPU regime on one GPU: per-rank shares of the headline batch
+        try:
+            if world == 1:
+                px = {}
+                for n_rank in (2, 4, 8):
+                    share = args.batch // n_rank
+                    sp = make(instance_slice=(0, share))
+                    sp.run(args.burn_in + args.warmup)
+                    elp, itp, flp, msp, _ = timed(sp, args.steps)
+                    px['n%d' % n_rank] = {'instances_per_gpu': share, 'ms_per_step': 1e3 * elp / args.steps, 'kernel_ms': msp,
+                                          'timesteps_per_s_this_gpu': share * args.steps / elp,
+                                          'implied_whole_job_value': args.batch * args.steps / elp,
+                                          'implied_strong_scaling_factor': elapsed / elp, 'qp_failures': int(flp)}
+                    del sp
+                px['note'] = ('NOT a multi-GPU measurement: rank 0\'s share of the %d-instance batch at N = 2 / 4 / 8 (instances [0, %d/N)) timed alone on this GPU; '
+                              'implied_* assume every rank takes as long as rank 0 and ignore the barrier.  Shares below 1408 instances (11 264 QPs) run the condensed '
+                              'solver qp_kernel<%d>, one wavefront per QP' % (args.batch, args.batch, T))
+                line['shard_proxy'] = px
+        except Exception as e:
+            line['shard_proxy'] = {'error': repr(e)}
         # -------------------------------------------------------------- the same workload at four times the batch: bound by work, not by the tail
         try:
             if world == 1:
@@ -464,7 +515,7 @@ def main():
             line['device_search'] = {'error': repr(e)}
         # the two multi-rank extras create a second communicator and a second batch: a rank that fails inside one of them would
         # leave the others waiting in a collective, so a watchdog on every rank gives them a deadline, after which rank 0 prints
-        # the line it has (headline + the extras already measured) and every rank leaves
+        # the line it has (headline + the extras already measured) and every rank leaves with exit code 3
         watchdog = None
         if world > 1:
             import threading
@@ -473,7 +524,7 @@ def main():
                 if rank == 0:
                     line.setdefault('agent_sharded', {'error': 'deadline of 180 s exceeded (a rank failed or the exchange hung)'})
                     print(json.dumps(line), flush=True)
-                os._exit(0)
+                os._exit(3)             # the line says what was measured; the exit code says the run did not end properly
             watchdog = threading.Timer(180.0, bail)
             watchdog.daemon = True
             watchdog.start()

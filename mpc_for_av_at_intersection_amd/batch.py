@@ -22,7 +22,8 @@ from .runtime import path_tables, Context, InteractionParams, MpcParams, MpcxErr
 class IntersectionBatch:
     def __init__(self, ctx: Context, params: MpcParams, ip: InteractionParams, routes: Sequence[np.ndarray], dl: float,
                  route_of_agent: np.ndarray, start_index: np.ndarray, v0: Optional[np.ndarray] = None,
-                 tuning: Optional[np.ndarray] = None, agent_shard: Optional[tuple] = None, exchange=None):
+                 tuning: Optional[np.ndarray] = None, agent_shard: Optional[tuple] = None, exchange=None,
+                 pose_offset: Optional[np.ndarray] = None):
         """routes: list of (n_r, 3) paths whose yaw column is already unwrapped (MPC.__init__, mpc.py:257);
         route_of_agent, start_index: integer arrays of shape (B, A); tuning: optional (B, 16) or (B*A, 16) array of
         MpcParams.tuning_row()s -- one cost/limit set per instance (or agent), the batched form of the reference's
@@ -32,7 +33,9 @@ class IntersectionBatch:
         rank*A/world .. of EVERY instance and sees the other ranks' agents only as moving obstacles, through one
         all-gather of 6-double agent states per step.  `exchange` says who moves the rows: 'rccl' (mpcx_allgather_states
         on the context's communicator, inside mpcx_closed_loop_run) or a callable local(B, A_loc, 6) -> pool(B, A, 6)
-        (sharding.torch_exchange: torch.distributed, used for gloo rehearsals)."""
+        (sharding.torch_exchange: torch.distributed, used for gloo rehearsals).
+        pose_offset: optional (B, A, 2) array (lateral offset [m] to the left of the path, heading error [rad]) added to the start
+        poses, which otherwise sit exactly on the path (config2_batch)."""
         # (a copy: the arc-length table below belongs to THIS batch's paths)
         ip = dataclasses.replace(ip, max_path_len=max(int(ip.max_path_len), max(len(r) for r in routes)))     # sizes the interaction kernel's LDS
         self.ctx, self.params, self.ip, self.dl = ctx, params, ip, float(dl)
@@ -54,6 +57,8 @@ class IntersectionBatch:
             start_index = start_index[:, a_lo:a_lo + a_loc]
             if v0 is not None:
                 v0 = np.asarray(v0, dtype=np.float64).reshape(-1, self.A_total)[:, a_lo:a_lo + a_loc]
+            if pose_offset is not None:
+                pose_offset = np.asarray(pose_offset, dtype=np.float64).reshape(-1, self.A_total, 2)[:, a_lo:a_lo + a_loc]
         self.B, self.A = route_of_agent.shape
         P = self.P = self.B * self.A
         T = params.T
@@ -75,6 +80,11 @@ class IntersectionBatch:
         st[:, 0], st[:, 1], st[:, 3] = pts[:, 0], pts[:, 1], pts[:, 2]
         if v0 is not None:
             st[:, 2] = np.asarray(v0, dtype=np.float64).reshape(-1)
+        if pose_offset is not None:
+            po = np.asarray(pose_offset, dtype=np.float64).reshape(P, 2)
+            st[:, 0] -= np.sin(pts[:, 2]) * po[:, 0]
+            st[:, 1] += np.cos(pts[:, 2]) * po[:, 0]
+            st[:, 3] += po[:, 1]
         dev = ctx.device
         self.state = ctx.f64(st)
         self.applied = torch.zeros((P, 2), dtype=torch.float64, device=dev)      # (steer, accel) of the last step
@@ -250,6 +260,43 @@ def synthetic_batch(ctx: Context, B: int, A: int = 8, T: int = 20, seed: int = 0
     ip = InteractionParams(cutoff_margin=4 * int(np.ceil(cd.radius / dl)), L=cd.distance_back_to_front_wheel, radius=cd.radius,
                            circle_centers=np.asarray(cd.circle_centers).ravel())
     return IntersectionBatch(ctx, params, ip, routes, dl, route_of_agent, start, agent_shard=agent_shard, exchange=exchange)
+
+
+ALL_STOCK_PAIRS = tuple((sp, ti) for sp in (1, 2, 3, 4) for ti in (1, 2, 3))
+
+
+def config2_batch(ctx: Context, B: int = 256, T: int = 20, seed: int = 0, routes=None, dl=None, cd=None, burn_in: int = 3,
+                  instance_slice: Optional[tuple] = None, mpc: Optional[MpcParams] = None):
+    """SURVEY section 8(d) config 2 (BASELINE configs[1]): B INDEPENDENT single-ego instances (no other agent, hence no coupling), drawn
+    with numpy.random.default_rng(seed): route uniform over the 12 stock A* paths (start_pos 1..4 x turn_indicator 1..3), arc position
+    s ~ U[0, len - T vmax dt / dl] path points, lateral offset ~ N(0, 0.3 m), heading error ~ N(0, 0.05 rad), v ~ U[0, 30/3.6 m/s];
+    `burn_in` (3) closed-loop steps are taken here so that every later step starts from the previous solution -- the generator
+    whose QPs have "realistic active sets" (acceleration bound when slow, steering-rate bound in the turns; lib/mpc.py:184-191).
+    `routes` must be the 12 paths of stock_routes(ctx, ALL_STOCK_PAIRS) when given.  The workload is a function of (B, T, seed) only;
+    instance_slice = (lo, hi) takes a rank's part of it."""
+    if routes is None:
+        routes, dl, cd = stock_routes(ctx, ALL_STOCK_PAIRS)
+    if len(routes) != len(ALL_STOCK_PAIRS):
+        raise ValueError('config2_batch draws from the %d stock routes, got %d' % (len(ALL_STOCK_PAIRS), len(routes)))
+    params = MpcParams(T=T, L=cd.distance_back_to_front_wheel) if mpc is None else dataclasses.replace(mpc, L=cd.distance_back_to_front_wheel)
+    rng = np.random.default_rng(seed)
+    route = rng.integers(0, len(routes), size=B)
+    lens = np.array([len(r) for r in routes])[route]
+    span = np.maximum(lens - params.T * params.max_speed * params.dt / dl, 1.0)
+    start = np.floor(rng.random(B) * span).astype(np.int64)
+    lateral = rng.normal(0.0, 0.3, B)
+    heading = rng.normal(0.0, 0.05, B)
+    v0 = rng.uniform(0.0, params.max_speed, B)
+    if instance_slice is not None:
+        lo, hi = instance_slice
+        route, start, lateral, heading, v0 = route[lo:hi], start[lo:hi], lateral[lo:hi], heading[lo:hi], v0[lo:hi]
+    ip = InteractionParams(cutoff_margin=4 * int(np.ceil(cd.radius / dl)), L=cd.distance_back_to_front_wheel, radius=cd.radius,
+                           circle_centers=np.asarray(cd.circle_centers).ravel())
+    sim = IntersectionBatch(ctx, params, ip, routes, dl, route[:, None], start[:, None], v0=v0[:, None],
+                            pose_offset=np.stack([lateral, heading], axis=1)[:, None, :])
+    if burn_in > 0:
+        sim.run(burn_in)
+    return sim
 
 
 def prius_frontier(ctx: Context, n: int = 1 << 20, seed: int = 0, extent: float = 40.0, free_space: bool = True, embed=None):

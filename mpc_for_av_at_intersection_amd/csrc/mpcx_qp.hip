@@ -138,8 +138,12 @@ __global__ __launch_bounds__(64, MPCX_OCC) void qp_kernel(QpArgs a) {
     constexpr int PRE = (N - 1 < MPCX_PRE) ? N - 1 : MPCX_PRE;   // column entries prefetched one column ahead in the factorisation
     constexpr int BCH = MPCX_BCH;          // same, stage pairs in the Hessian build (8 doubles each)
     __shared__ QpShared<NT> sh;
-    const int lane = threadIdx.x;
   for (int guard = 0; guard <= a.B; guard++) {      // every wavefront leaves after at most B+1 tickets (bounded by construction)
+    // the lane index is made opaque once per problem: everything derived from it (table indices, row masks, tile maps: ~40 values) is
+    // then recomputed per problem -- a few dozen integer instructions -- instead of being hoisted out of the work loop, where it
+    // stayed live across the whole solve and was spilled (164 B/lane of scratch in the T = 20 build, written by every wavefront)
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
     int b = 0;
     if (lane == 0) b = atomicAdd(a.ticket, 1);
     b = __builtin_amdgcn_readfirstlane(b);

@@ -228,35 +228,41 @@ def test_expansion_one_million_nodes(ctx):
 
 
 def test_config2_256_independent_instances_closed_loop(ctx):
-    """BASELINE configs[1]: batch = 256 independent single-ego instances, N = 20, float64 -- 12 closed-loop steps, every
-    agent replayed step by step on the oracle from the device state of the previous step."""
-    from mpc_for_av_at_intersection_amd.batch import stock_routes, synthetic_batch
+    """BASELINE configs[1] on the workload SURVEY 8(d) config 2 defines (batch.config2_batch: route uniform over the 12 stock paths,
+    arc position uniform, lateral offset N(0, 0.3 m), heading error N(0, 0.05 rad), v ~ U[0, 8.33], seed 0): batch = 256 independent
+    single-ego instances, N = 20, float64 -- the 3 burn-in steps and 12 more, EVERY agent of EVERY step replayed on the oracle from the
+    device state of the previous step (decisions and statuses identical, solutions within one 2e-7), the plant update included."""
+    from mpc_for_av_at_intersection_amd.batch import ALL_STOCK_PAIRS, config2_batch, stock_routes
     from oracle import oracle_py as orc
-    routes, dl, cd = stock_routes(ctx)
+    routes, dl, cd = stock_routes(ctx, ALL_STOCK_PAIRS)
     B, T = 256, 20
-    sim = synthetic_batch(ctx, B=B, A=1, T=T, seed=11, routes=routes, dl=dl, cd=cd)
-    tab = sim.path.cpu().numpy(); off = sim.path_off.cpu().numpy(); ln = sim.path_len.cpu().numpy()
+    sim = config2_batch(ctx, B=B, T=T, seed=0, routes=routes, dl=dl, cd=cd, burn_in=0)
+    # the generator itself: perturbed poses (not on the path), speeds over the whole range, all 12 routes drawn
+    st0 = sim.state.cpu().numpy()
+    tab = sim.path.cpu().numpy(); off = sim.path_off.cpu().numpy()
+    on_path = tab[off + sim.traj_idx.cpu().numpy()]
+    lat = np.hypot(st0[:, 0] - on_path[:, 0], st0[:, 1] - on_path[:, 1])
+    assert 0.15 < lat.mean() < 0.35 and 0.02 < np.abs(st0[:, 3] - on_path[:, 2]).mean() < 0.06
+    assert st0[:, 2].min() < 0.5 and st0[:, 2].max() > 7.8 and len(np.unique(off)) == 12
     po = orc.MpcParams(T=T, L=sim.params.L)
-    centers = np.asarray(sim.ip.circle_centers).reshape(2, 2)
-    worst = 0.0
+    worst, constrained, n = 0.0, 0, 0
     before = sim.snapshot()
-    for step in range(12):
+    for step in range(15):
         sim.step()
         after = sim.snapshot()
         assert (after['status'] == 0).all()
-        for q in range(0, B, 4 if step else 1):          # all agents on the first step, every 4th afterwards
-            r = orc.agent_step(po, tab[off[q]:off[q] + ln[q]], sim.dl, before['state'][q], np.zeros((0, 6)), int(before['traj_idx'][q]),
-                               int(before['prev_cut'][q]), int(before['target_ind'][q]), before['u'][q] if step else None,
-                               centers, sim.ip.radius, sim.ip.cutoff_margin)
-            assert r['traj_idx'] == after['traj_idx'][q] and r['target_ind'] == after['target_ind'][q] and r['cut'] == ln[q]
-            assert np.array_equal(r['xref'], after['xref'][q]) and np.array_equal(r['re'], after['reaches_end'][q])
-            worst = max(worst, np.abs(r['sol'].u - after['u'][q]).max(), np.abs(r['xbar'] - after['xbar'][q]).max())
-            # plant: the oracle's Euler step from the same control reproduces the device state
-            nxt = orc.plant_step(po, before['state'][q], r['sol'].u[0, 0], r['sol'].u[1, 0])
+        w, it_diff, failed = _replay_all_on_oracle(sim, before, after, threads=8)
+        assert it_diff == 0 and failed == 0
+        worst = max(worst, w)
+        for q in range(0, B, 8):                         # plant: the oracle's Euler step from the same control reproduces the device state
+            nxt = orc.plant_step(po, before['state'][q], after['u'][q, 0, 0], after['u'][q, 1, 0])
             assert np.abs(nxt - after['state'][q]).max() < 1e-9
+        if step >= 3:
+            constrained += int((after['iters'] > 0).sum()); n += B
         before = after
-    assert worst < 2e-7, worst
-    assert (after['state'][:, 2] > 1.0).all()            # everybody got going
+    print('config 2: 15 steps x 256 agents vs oracle: worst %.2e; %.0f %% of the QPs after burn-in have active constraints' % (worst, 100.0 * constrained / n))
+    assert constrained > 0.2 * n                         # "realistic active sets": not a batch of unconstrained minimisers
+    sim.check()
 
 
 def test_closed_loop_run_equals_staged_path_and_graph_replay(ctx):
