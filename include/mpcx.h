@@ -118,27 +118,40 @@ int32_t mpcx_expand_batch(mpcx_ctx *ctx, const mpcx_search_model *m, int32_t n_n
                           const double *nodes_cs /*n,2: cos,sin of nodes[:,2], or NULL = device sincos*/,
                           double *nbr /*n,P,3*/, double *cost /*n,P*/, uint8_t *collide /*n,P*/);
 
-/* ---- lib/a_star.py:31-78 `AStar.run` + lib/motion_primitive_search.py:64-75,87-121 (is_goal, distance_to_goal, neighbor_function) and
- * lib/motion_primitive_search_modified.py:80-89 for MANY independent searches, open list and closed set resident on the device: one
- * wavefront per search, no host work between expansions.  The pop order is the reference's (tuples (g + h, g, node, predecessor)
- * compared field by field, node identity = float equality), which needs the reference's bits in every number: cos / sin of a node's
- * heading come from a table the host fills with numpy (cs_theta ascending, cs_val (cos, sin)): a heading missing from it ends the
- * search with MPCX_ASTAR_MISS and the heading in buffers.miss; the `modified` heuristic squares with x * x where Python's ** is libm
- * pow (one ulp apart for ~0.08 % of arguments), logs the h of every push, and takes corrections from an override table (hov_node sorted
- * as tuples, hov_h) the host fills after checking the log with Python floats.  models / searches are HOST arrays; every pointer inside
+/* ---- lib/a_star.py:31-78 `AStar.run` + lib/motion_primitive_search.py:64-75,87-121 (is_goal, distance_to_goal, neighbor_function),
+ * lib/motion_primitive_search_modified.py:80-89, lib/motion_primitive_search_multi_lane.py:56-108,155-181,226-237,
+ * lib/motion_primitive_search_roundabout.py:131-157,212 and lib/motion_primitive_search_single_lane.py:145-162,218 for MANY independent
+ * searches, open list and closed set resident on the device: one wavefront per search, no host work between expansions.  The pop order
+ * is the reference's (tuples (g + h, g, node, predecessor) compared field by field, node identity = float equality), which needs the
+ * reference's bits in every number: cos / sin of a node's heading come from a table the host fills with numpy (cs_theta ascending,
+ * cs_val (cos, sin)): a heading missing from it ends the search with MPCX_ASTAR_MISS and the heading in buffers.miss.  Heuristic and
+ * edge values are evaluated with un-fused IEEE operations; where the reference goes through libm pow (Python's x ** 2: one ulp from
+ * x * x for ~0.08 % of arguments) or BLAS (np.linalg.norm) the device value can differ by an ulp, so the kernel LOGS every value it
+ * used (successor log below), the host re-evaluates them with the reference's own expressions and hands the few that differ back in a
+ * PER-SEARCH override table: rows (x, y, theta, kind) sorted as tuples inside each search's slice [ov_off, ov_off + ov_cnt) of
+ * ov_key / ov_val; kind = -1: ov_val is h(node); kind = k >= 0: ov_val is the edge value of primitive k leaving `node`.  Overrides are
+ * never consulted for MPCX_ASTAR_BASE (its arithmetic is exact on the device).  models / searches are HOST arrays; every pointer inside
  * mpcx_astar_buffers is a DEVICE pointer to caller-owned memory: heap n x heap_cap x 10 doubles, table n x table_cap x 8 doubles
  * FILLED WITH NaN (table_cap a power of two), log n x log_cap x 8 (node, g, h, predecessor per expansion: a_star.py:52), push_log
- * n x push_cap x 4 (node, h per push), path n x path_cap x 3 and path_prim n x path_cap (goal first, primitive that led to each node,
- * -1 at the start), cost / miss / status / n_exp / n_push / path_len n each. */
-enum { MPCX_ASTAR_BASE = 0, MPCX_ASTAR_MODIFIED = 1 };
-enum { MPCX_ASTAR_FOUND = 0, MPCX_ASTAR_EXHAUSTED = 1 /* "No solution found." */, MPCX_ASTAR_CAPACITY = 2, MPCX_ASTAR_MISS = 3 };
+ * n x push_cap x 8 -- the successor log: (node, h, edge value, index of the expansion it came from, primitive id, g) per PUSH for
+ * BASE / MODIFIED and per FREE successor for the other variants (h = NaN if the successor was not pushed) --, path n x path_cap x 3 and
+ * path_prim n x path_cap (goal first, primitive that led to each node, -1 at the start), cost / miss / status / n_exp / n_push /
+ * path_len n each.  A path longer than path_cap ends in MPCX_ASTAR_PATH_CAPACITY (nothing is truncated silently). */
+enum { MPCX_ASTAR_BASE = 0, MPCX_ASTAR_MODIFIED = 1, MPCX_ASTAR_MULTI_LANE = 2, MPCX_ASTAR_ROUNDABOUT = 3, MPCX_ASTAR_SINGLE_LANE = 4 };
+enum { MPCX_ASTAR_FOUND = 0, MPCX_ASTAR_EXHAUSTED = 1 /* "No solution found." */, MPCX_ASTAR_CAPACITY = 2, MPCX_ASTAR_MISS = 3,
+       MPCX_ASTAR_PATH_CAPACITY = 4 };
 typedef struct {
     double start[3];
     double goal_box[4];         /* BoxObstacle.xy1, xy2 of scenario.goal_area */
     double goal_point[3];
     double allowed_dtheta;      /* scenario.allowed_goal_theta_difference */
-    int32_t variant;            /* MPCX_ASTAR_BASE / MPCX_ASTAR_MODIFIED */
+    double wh[5];               /* MULTI_LANE: wh_dist, wh_theta, wh_steering, wh_obstacle, wh_center (_multi_lane.py:24) */
+    double wc[4];               /* MULTI_LANE: wc_dist, wc_steering, wc_obstacle, wc_center (_multi_lane.py:26) */
+    const double *hp_norm;      /* DEVICE, one per half-plane row of the model: (a**2 + b**2)**0.5 as the host's Python evaluates it
+                                 * (_multi_lane.py:95); needed by ROUNDABOUT / SINGLE_LANE and by MULTI_LANE with wh_obstacle != 0 */
+    int32_t variant;            /* MPCX_ASTAR_BASE ... MPCX_ASTAR_SINGLE_LANE */
     int32_t max_expansions;
+    int32_t ov_off, ov_cnt;     /* this search's slice of the override table */
 } mpcx_astar_search;
 typedef struct {
     int32_t heap_cap, table_cap, log_cap, push_cap, path_cap;
@@ -147,7 +160,7 @@ typedef struct {
 } mpcx_astar_buffers;
 int32_t mpcx_astar_batch(mpcx_ctx *ctx, int32_t n_search, const mpcx_search_model *const *models, const mpcx_astar_search *searches,
                          int32_t n_cs, const double *cs_theta, const double *cs_val,
-                         int32_t n_hov, const double *hov_node, const double *hov_h, const mpcx_astar_buffers *buffers);
+                         int32_t n_ov, const double *ov_key /*n_ov,4*/, const double *ov_val /*n_ov*/, const mpcx_astar_buffers *buffers);
 
 /* ---- the same expansion for SEVERAL searches in one launch (many independent planners running concurrently): segment s = nodes
  * seg_off[s] .. seg_off[s+1]-1 of the node table (HOST array, n_seg+1 entries), expanded against models[s] (HOST array of

@@ -44,7 +44,8 @@ class ClosedLoopC(C.Structure):
 class AstarSearchC(C.Structure):
     """mirror of mpcx_astar_search (include/mpcx.h)"""
     _fields_ = [('start', C.c_double * 3), ('goal_box', C.c_double * 4), ('goal_point', C.c_double * 3), ('allowed_dtheta', C.c_double),
-                ('variant', C.c_int32), ('max_expansions', C.c_int32)]
+                ('wh', C.c_double * 5), ('wc', C.c_double * 4), ('hp_norm', C.c_void_p),
+                ('variant', C.c_int32), ('max_expansions', C.c_int32), ('ov_off', C.c_int32), ('ov_cnt', C.c_int32)]
 
 
 class AstarBuffersC(C.Structure):
@@ -53,8 +54,16 @@ class AstarBuffersC(C.Structure):
                 [(n, C.c_void_p) for n in ('heap', 'table', 'log', 'push_log', 'path', 'cost', 'miss', 'status', 'n_exp', 'n_push', 'path_len', 'path_prim')])
 
 
-ASTAR_BASE, ASTAR_MODIFIED = 0, 1
-ASTAR_FOUND, ASTAR_EXHAUSTED, ASTAR_CAPACITY, ASTAR_MISS = 0, 1, 2, 3
+# the same struct as a numpy record (plan_many_device fills thousands of rows without a Python loop per field)
+import numpy as _np
+ASTAR_SEARCH_DTYPE = _np.dtype([('start', '<f8', 3), ('goal_box', '<f8', 4), ('goal_point', '<f8', 3), ('allowed_dtheta', '<f8'),
+                                ('wh', '<f8', 5), ('wc', '<f8', 4), ('hp_norm', '<u8'), ('variant', '<i4'), ('max_expansions', '<i4'),
+                                ('ov_off', '<i4'), ('ov_cnt', '<i4')])
+assert ASTAR_SEARCH_DTYPE.itemsize == C.sizeof(AstarSearchC)
+ASTAR_BASE, ASTAR_MODIFIED, ASTAR_MULTI_LANE, ASTAR_ROUNDABOUT, ASTAR_SINGLE_LANE = 0, 1, 2, 3, 4
+ASTAR_VARIANTS = {'base': ASTAR_BASE, 'modified': ASTAR_MODIFIED, 'multi_lane': ASTAR_MULTI_LANE, 'roundabout': ASTAR_ROUNDABOUT,
+                  'single_lane': ASTAR_SINGLE_LANE}
+ASTAR_FOUND, ASTAR_EXHAUSTED, ASTAR_CAPACITY, ASTAR_MISS, ASTAR_PATH_CAPACITY = 0, 1, 2, 3, 4
 COMM_ID_BYTES = 128
 SHARD_INSTANCES, SHARD_AGENTS = 1, 2
 

@@ -2,8 +2,9 @@
 // generation of MANY independent searches live on the GPU, one wavefront per search, no host work between expansions.
 //
 // Replaces (paths relative to /root/reference/main) lib/a_star.py:31-78 `AStar.run` together with
-// lib/motion_primitive_search.py:64-75,87-121 (is_goal, distance_to_goal, neighbor_function) and
-// lib/motion_primitive_search_modified.py:80-89 (the heuristic every stock MPC scenario uses).
+// lib/motion_primitive_search.py:64-75,87-121 (is_goal, distance_to_goal, neighbor_function),
+// lib/motion_primitive_search_modified.py:80-89 (the heuristic every stock MPC scenario uses) and the weighted heuristic / edge terms of
+// lib/motion_primitive_search_multi_lane.py:56-108,155-181,226-237, _roundabout.py:131-157,212 and _single_lane.py:145-162,218.
 //
 // Exactness.  The reference's pop order is the order of the Python tuples (g + h, g, node, predecessor) and its node identity is
 // float equality of (x, y, theta), so every number that enters them must come out with the reference's bits:
@@ -15,7 +16,11 @@
 //    reproduced exactly with un-fused IEEE operations;
 //  * the `modified` heuristic squares with Python's `**`, i.e. libm pow(x, 2.0), which is NOT always the correctly rounded x * x (one ulp
 //    off for ~0.08 % of arguments).  The kernel uses x * x, logs the h of every push, the host re-evaluates them with Python
-//    floats and hands the few that differ back as an override table (sorted by node); the search is run again with it.
+//    floats and hands the few that differ back as an override table (per search, sorted by node); the search is run again with it;
+//  * the edge values of the multi-lane / roundabout / single-lane variants (steering change through Python's float %, 1 / distance to
+//    the nearest half-plane with the row norms (a**2 + b**2)**0.5 supplied by the host, np.linalg.norm) enter g and therefore the key:
+//    evaluated with un-fused IEEE operations, logged for EVERY free successor (pushed or not: a wrong edge value could also have
+//    suppressed a push) and checked / overridden by the host the same way.
 // The heap is 8-ary so that a wavefront sifts with one level per memory round trip (children compared by eight lanes, minimum by
 // shuffles); keys are compared as the tuples are, field by field.
 #include "mpcx_expand_core.h"
@@ -26,17 +31,20 @@ namespace mpcx {
 constexpr int HEAP_ARITY = 8;
 constexpr int HE = 10;      // doubles per heap entry: f, g, node[3], pred[3], primitive id, (pad)
 constexpr int TE = 8;       // doubles per closed-set entry: node[3], g, pred[3], primitive id
+constexpr int PLE = 8;      // doubles per successor-log entry: node[3], h (NaN: not pushed), edge value, expansion index, primitive id, g
 
 struct AstarArgs {
     ExpandArgs model;       // tables of this search's model (nodes / outputs unused)
     mpcx_astar_search sp;
+    const double *hp_all;   // ALL half-plane rows of the model (a, b, c), n_rows_all of them: the obstacle-distance terms
+    int n_rows_all;
 };
 
 struct AstarIO {
     int n_search;
     const AstarArgs *searches;
     int n_cs; const double *cs_theta, *cs_val;
-    int n_hov; const double *hov_node, *hov_h;
+    int n_ov; const double *ov_key, *ov_val;
     int heap_cap, table_cap, log_cap, push_cap, path_cap;
     double *heap, *table, *log, *push_log, *path, *cost, *miss;
     int32_t *status, *n_exp, *n_push, *path_len, *path_prim;
@@ -89,14 +97,14 @@ __device__ __forceinline__ int sorted_find(const double *tab, int n, double v) {
     }
     return -1;
 }
-// override table of the heuristic: nodes sorted as tuples
-__device__ __forceinline__ int node_find(const double *tab, int n, double x, double y, double t) {
+// override table (one search's slice): rows (x, y, theta, kind) sorted as tuples
+__device__ __forceinline__ int key4_find(const double *tab, int n, double x, double y, double t, double kind) {
     int lo = 0, hi = n - 1;
     while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
-        const double *m = tab + 3 * (size_t)mid;
-        if (m[0] == x && m[1] == y && m[2] == t) return mid;
-        const bool less = m[0] < x || (m[0] == x && (m[1] < y || (m[1] == y && m[2] < t)));
+        const double *m = tab + 4 * (size_t)mid;
+        if (m[0] == x && m[1] == y && m[2] == t && m[3] == kind) return mid;
+        const bool less = m[0] < x || (m[0] == x && (m[1] < y || (m[1] == y && (m[2] < t || (m[2] == t && m[3] < kind)))));
         if (less) lo = mid + 1; else hi = mid - 1;
     }
     return -1;
@@ -112,7 +120,39 @@ __device__ __forceinline__ double box_distance(const double *box, double x, doub
     return __dsqrt_rn(__dadd_rn(mul_rn(dx, dx), mul_rn(dy, dy)));
 }
 
-__device__ __forceinline__ double heuristic(const mpcx_astar_search &sp, double x, double y, double t) {
+// Python's float % for a positive divisor (floatobject.c float_rem: fmod, then the result takes the divisor's sign)
+__device__ __forceinline__ double py_mod_pos(double x, double y) {
+    double m = fmod(x, y);
+    if (m != 0.0) { if (m < 0.0) m = __dadd_rn(m, y); } else m = 0.0;
+    return m;
+}
+// calculate_steering_change_cost(current, next, 1.0) (_multi_lane.py:56-76): |((next - current + pi) % (2 pi)) - pi|
+__device__ __forceinline__ double steering_change(double current_th, double next_th) {
+    const double pi = 3.141592653589793, tau = 6.283185307179586;
+    const double d = __dadd_rn(next_th, -current_th);
+    return fabs(__dadd_rn(py_mod_pos(__dadd_rn(d, pi), tau), -pi));
+}
+// distance_to_nearest_obstacle (_multi_lane.py:78-108): min over every half-plane row of |a x + b y + c| / (a**2 + b**2)**0.5; the whole
+// wavefront calls it with the same point, lane l takes rows l, l + 64, ...
+__device__ __forceinline__ double nearest_obstacle(const double *hp, const double *norm, int n_rows, double x, double y, int lane) {
+    double best = INFINITY;
+    for (int r = lane; r < n_rows; r += WAVE) {
+        const double v = fabs(__dadd_rn(__dadd_rn(mul_rn(hp[3 * r], x), mul_rn(hp[3 * r + 1], y)), hp[3 * r + 2])) / norm[r];
+        best = v < best ? v : best;
+    }
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const double o = __shfl_xor(best, d, WAVE);
+        best = o < best ? o : best;
+    }
+    return best;
+}
+__host__ __device__ __forceinline__ bool needs_obstacle_term(const mpcx_astar_search &sp) {
+    return sp.variant == MPCX_ASTAR_ROUNDABOUT || sp.variant == MPCX_ASTAR_SINGLE_LANE || (sp.variant == MPCX_ASTAR_MULTI_LANE && sp.wh[3] != 0.0);
+}
+
+// distance_to_goal of the search's variant at node (x, y, t); obst = 1 / distance to the nearest obstacle there (or 0 if the variant has no such term)
+__device__ __forceinline__ double heuristic(const mpcx_astar_search &sp, double x, double y, double t, double obst) {
     if (sp.variant == MPCX_ASTAR_BASE) {            // motion_primitive_search.py:71-75
         const double dxy = box_distance(sp.goal_box, x, y);
         const double dth = fmax(0.0, __dadd_rn(fabs(__dadd_rn(t, -sp.goal_point[2])), -sp.allowed_dtheta));
@@ -124,7 +164,32 @@ __device__ __forceinline__ double heuristic(const mpcx_astar_search &sp, double 
     const double ad = fabs(__dadd_rn(t, -sp.goal_point[2]));
     const double alt = __dadd_rn(ad, -__ddiv_rn(sp.allowed_dtheta, 2.0));
     const double dth = alt < ad ? alt : ad;          // Python's min(a, b): b only if b < a
-    return __dadd_rn(dxy, mul_rn(2.7, dth));
+    if (sp.variant == MPCX_ASTAR_MODIFIED || sp.variant == MPCX_ASTAR_ROUNDABOUT)     // _roundabout.py:155: the same two terms
+        return __dadd_rn(dxy, mul_rn(2.7, dth));
+    const double steer = steering_change(t, sp.goal_point[2]);
+    if (sp.variant == MPCX_ASTAR_SINGLE_LANE)       // _single_lane.py:160
+        return __dadd_rn(__dadd_rn(dxy, mul_rn(2.7, dth)), mul_rn(15.0, steer));
+    // _multi_lane.py:155-181, terms added left to right
+    const double centre = sp.wh[4] != 0.0 ? __dsqrt_rn(__dadd_rn(mul_rn(x, x), mul_rn(y, y))) : 0.0;
+    double h = __dadd_rn(mul_rn(sp.wh[0], dxy), mul_rn(sp.wh[1], dth));
+    h = __dadd_rn(h, mul_rn(sp.wh[2], steer));
+    h = __dadd_rn(h, mul_rn(sp.wh[3], obst));
+    return __dadd_rn(h, mul_rn(sp.wh[4], centre));
+}
+
+// the edge value neighbor_function yields for primitive k (length `len`) from heading nth to the successor (sx, sy, sth)
+__device__ __forceinline__ double edge_value(const mpcx_astar_search &sp, double len, double nth, double sx, double sy, double sth, double obst) {
+    if (sp.variant == MPCX_ASTAR_BASE || sp.variant == MPCX_ASTAR_MODIFIED) return len;       // motion_primitive_search.py:118
+    const double steer = steering_change(nth, sth);
+    if (sp.variant == MPCX_ASTAR_ROUNDABOUT)        // _roundabout.py:212: length + 0.1 * obstacle + 5 * steering
+        return __dadd_rn(__dadd_rn(len, mul_rn(0.1, obst)), mul_rn(5.0, steer));
+    if (sp.variant == MPCX_ASTAR_SINGLE_LANE)       // _single_lane.py:218: length + 5 * steering + 0.1 * obstacle
+        return __dadd_rn(__dadd_rn(len, mul_rn(5.0, steer)), mul_rn(0.1, obst));
+    // _multi_lane.py:226-237 (np.linalg.norm([x, y]) taken as sqrt(x*x + y*y); the host check corrects the rare ulp)
+    const double centre = sp.wc[3] != 0.0 ? __dsqrt_rn(__dadd_rn(mul_rn(sx, sx), mul_rn(sy, sy))) : 0.0;
+    double e = __dadd_rn(mul_rn(sp.wc[0], len), mul_rn(sp.wc[1], steer));
+    e = __dadd_rn(e, mul_rn(sp.wc[2], obst));
+    return __dadd_rn(e, mul_rn(sp.wc[3], centre));
 }
 
 __global__ __launch_bounds__(64) void astar_kernel(AstarIO io) {
@@ -137,8 +202,13 @@ __global__ __launch_bounds__(64) void astar_kernel(AstarIO io) {
     double *heap = io.heap + (size_t)sidx * io.heap_cap * HE;
     double *tab = io.table + (size_t)sidx * io.table_cap * TE;
     double *log = io.log + (size_t)sidx * io.log_cap * 8;
-    double *plog = io.push_log + (size_t)sidx * io.push_cap * 4;
-    int n_heap = 0, n_exp = 0, n_push = 0, status = MPCX_ASTAR_EXHAUSTED;
+    double *plog = io.push_log + (size_t)sidx * io.push_cap * PLE;
+    // pessimistic until an exit says otherwise: a loop that runs out of passes has run out of room, not out of nodes
+    int n_heap = 0, n_exp = 0, n_push = 0, status = MPCX_ASTAR_CAPACITY;
+    const bool log_all = sp.variant >= MPCX_ASTAR_MULTI_LANE;     // variants whose edge values are computed: every free successor is logged
+    const bool want_obst = needs_obstacle_term(sp);
+    const bool use_ov = sp.ov_cnt > 0 && sp.variant != MPCX_ASTAR_BASE;
+    const double *ovk = io.ov_key + 4 * (size_t)sp.ov_off, *ovv = io.ov_val + (size_t)sp.ov_off;
     double result_cost = 0.0, goal_node[3] = {0.0, 0.0, 0.0};
 
     // q = [(0, 0, start, start)]
@@ -150,7 +220,7 @@ __global__ __launch_bounds__(64) void astar_kernel(AstarIO io) {
     n_heap = 1;
     __syncthreads();
 
-    for (long guard = 0; guard < (long)io.heap_cap + 8; guard++) {      // every pass pops one entry: bounded by the pushes the heap can hold
+    for (long guard = 0; guard < (long)io.push_cap + 2; guard++) {      // every pass pops one entry: bounded by the pushes the log can hold (+ the start)
         if (n_heap == 0) { status = MPCX_ASTAR_EXHAUSTED; break; }
         // ---------------------------------------------------------------- heappop: the root leaves, the last entry sifts down from the root
         double top[HE];
@@ -238,19 +308,46 @@ __global__ __launch_bounds__(64) void astar_kernel(AstarIO io) {
             const bool free_k = __shfl((int)hit, k, WAVE) == 0;
             const double sx = __shfl(pose[0], k, WAVE), sy = __shfl(pose[1], k, WAVE), sth = __shfl(pose[2], k, WAVE);
             if (!free_k) continue;
-            const double ng = __dadd_rn(g, a.edge_cost[k]);      // neighbor_g = g + edge_value
+            double obst = 0.0;
+            if (want_obst) {
+                const double dn = nearest_obstacle(sa.hp_all, sp.hp_norm, sa.n_rows_all, sx, sy, lane);
+                obst = dn != 0.0 ? 1.0 / dn : INFINITY;          // 1 / d if d else float('inf')
+            }
+            double edge = edge_value(sp, a.edge_cost[k], nth, sx, sy, sth, obst);
+            if (use_ov && log_all) {
+                const int ov = key4_find(ovk, sp.ov_cnt, nx, ny, nth, (double)k);
+                if (ov >= 0) edge = ovv[ov];
+            }
+            const double ng = __dadd_rn(g, edge);                // neighbor_g = g + edge_value
+            int li = -1;
+            if (log_all) {
+                if (n_push >= io.push_cap) { overflow = true; break; }
+                li = n_push++;
+                if (lane == 0) {
+                    double *pl = plog + (size_t)li * PLE;
+                    pl[0] = sx; pl[1] = sy; pl[2] = sth; pl[3] = NAN; pl[4] = edge; pl[5] = (double)(n_exp - 1); pl[6] = (double)k; pl[7] = ng;
+                }
+            }
             bool seen;
             const int sl = table_find(tab, io.table_cap, sx, sy, sth, seen);
             if (sl < 0) { overflow = true; break; }
             if (seen && !(ng < tab[(size_t)sl * TE + 3])) continue;
-            double h = heuristic(sp, sx, sy, sth);
-            if (io.n_hov > 0) {
-                const int ov = node_find(io.hov_node, io.n_hov, sx, sy, sth);
-                if (ov >= 0) h = io.hov_h[ov];
+            double h = heuristic(sp, sx, sy, sth, obst);
+            if (use_ov) {
+                const int ov = key4_find(ovk, sp.ov_cnt, sx, sy, sth, -1.0);
+                if (ov >= 0) h = ovv[ov];
             }
-            if (n_heap >= io.heap_cap || n_push >= io.push_cap) { overflow = true; break; }
-            if (lane == 0) { double *pl = plog + (size_t)n_push * 4; pl[0] = sx; pl[1] = sy; pl[2] = sth; pl[3] = h; }
-            n_push++;
+            if (n_heap >= io.heap_cap) { overflow = true; break; }
+            if (!log_all) {
+                if (n_push >= io.push_cap) { overflow = true; break; }
+                li = n_push++;
+                if (lane == 0) {
+                    double *pl = plog + (size_t)li * PLE;
+                    pl[0] = sx; pl[1] = sy; pl[2] = sth; pl[3] = h; pl[4] = edge; pl[5] = (double)(n_exp - 1); pl[6] = (double)k; pl[7] = ng;
+                }
+            } else if (lane == 0) {
+                plog[(size_t)li * PLE + 3] = h;
+            }
             // heappush: sift up from the end
             double nk[HE] = {__dadd_rn(ng, h), ng, sx, sy, sth, nx, ny, nth, (double)k, 0.0};
             int pos = n_heap++;
@@ -279,16 +376,18 @@ __global__ __launch_bounds__(64) void astar_kernel(AstarIO io) {
         double *path = io.path + (size_t)sidx * io.path_cap * 3;
         int32_t *pprim = io.path_prim + (size_t)sidx * io.path_cap;
         double cx = goal_node[0], cy = goal_node[1], cth = goal_node[2];
+        bool at_start = false;
         for (; plen < io.path_cap; plen++) {
             bool f;
             const int sl = table_find(tab, io.table_cap, cx, cy, cth, f);
             path[3 * plen] = cx; path[3 * plen + 1] = cy; path[3 * plen + 2] = cth;
             pprim[plen] = (f && sl >= 0) ? (int32_t)tab[(size_t)sl * TE + 7] : -1;
             if (!f || sl < 0) break;
-            if (cx == sp.start[0] && cy == sp.start[1] && cth == sp.start[2]) { plen++; break; }
+            if (cx == sp.start[0] && cy == sp.start[1] && cth == sp.start[2]) { plen++; at_start = true; break; }
             const double *e = tab + (size_t)sl * TE;
             cx = e[4]; cy = e[5]; cth = e[6];
         }
+        if (!at_start) status = MPCX_ASTAR_PATH_CAPACITY;       // longer than path_cap (or a broken chain): never a silently truncated path
     }
     if (lane == 0) {
         io.status[sidx] = status; io.n_exp[sidx] = n_exp; io.n_push[sidx] = n_push; io.cost[sidx] = result_cost; io.path_len[sidx] = plen;
@@ -299,11 +398,11 @@ __global__ __launch_bounds__(64) void astar_kernel(AstarIO io) {
 
 extern "C" int32_t mpcx_astar_batch(mpcx_ctx *ctx, int32_t n_search, const mpcx_search_model *const *models, const mpcx_astar_search *searches,
                                     int32_t n_cs, const double *cs_theta, const double *cs_val,
-                                    int32_t n_hov, const double *hov_node, const double *hov_h,
+                                    int32_t n_ov, const double *ov_key, const double *ov_val,
                                     const mpcx_astar_buffers *b) {
     if (!ctx) return MPCX_E_INVALID;
     if (n_search == 0) return MPCX_OK;
-    if (n_search < 0 || !models || !searches || !b || n_cs < 0 || (n_cs > 0 && (!cs_theta || !cs_val)) || n_hov < 0 || (n_hov > 0 && (!hov_node || !hov_h)))
+    if (n_search < 0 || !models || !searches || !b || n_cs < 0 || (n_cs > 0 && (!cs_theta || !cs_val)) || n_ov < 0 || (n_ov > 0 && (!ov_key || !ov_val)))
         return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: null table or negative count");
     if (b->heap_cap < 16 || b->table_cap < 16 || (b->table_cap & (b->table_cap - 1)) || b->log_cap < 1 || b->push_cap < 1 || b->path_cap < 2 ||
         !b->heap || !b->table || !b->log || !b->push_log || !b->path || !b->path_prim || !b->cost || !b->miss || !b->status || !b->n_exp || !b->n_push || !b->path_len)
@@ -311,13 +410,20 @@ extern "C" int32_t mpcx_astar_batch(mpcx_ctx *ctx, int32_t n_search, const mpcx_
     std::vector<mpcx::AstarArgs> host((size_t)n_search);
     for (int i = 0; i < n_search; i++) {
         const mpcx_search_model *m = models[i];
+        const mpcx_astar_search &sp = searches[i];
         if (!m) return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: search %d has no model", i);
         if (m->n_prim > 64) return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: more than 64 primitives");
-        if (searches[i].variant != MPCX_ASTAR_BASE && searches[i].variant != MPCX_ASTAR_MODIFIED)
-            return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: search %d: variant must be MPCX_ASTAR_BASE or MPCX_ASTAR_MODIFIED", i);
+        if (sp.variant < MPCX_ASTAR_BASE || sp.variant > MPCX_ASTAR_SINGLE_LANE)
+            return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: search %d: unknown variant %d", i, sp.variant);
+        if (sp.ov_cnt < 0 || sp.ov_off < 0 || (long)sp.ov_off + sp.ov_cnt > n_ov)
+            return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: search %d: override slice [%d, %d) outside the table of %d rows", i, sp.ov_off, sp.ov_off + sp.ov_cnt, n_ov);
+        if (mpcx::needs_obstacle_term(sp) && m->n_rows > 0 && !sp.hp_norm)
+            return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: search %d: the variant has an obstacle-distance term and needs hp_norm", i);
         host[i].model = mpcx::ExpandArgs{m->n_prim, m->n_obst, m->n_pts, m->n_rest, 0, m->d_tmpl_off, m->d_rest_off, m->d_tmpl_xy, m->d_last_pose,
                                          m->d_edge_cost, m->d_rest, m->d_aabb, nullptr, nullptr, nullptr, nullptr, nullptr};
-        host[i].sp = searches[i];
+        host[i].sp = sp;
+        host[i].hp_all = m->d_hp;
+        host[i].n_rows_all = m->n_rows;
     }
     const size_t need = host.size() * sizeof(mpcx::AstarArgs);
     if (need > ctx->multi_cap) {
@@ -329,7 +435,7 @@ extern "C" int32_t mpcx_astar_batch(mpcx_ctx *ctx, int32_t n_search, const mpcx_
     if (hipMemcpyAsync(ctx->multi, host.data(), need, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)      // `host` goes out of scope
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "astar_batch: descriptor upload failed");
-    mpcx::AstarIO io{n_search, (const mpcx::AstarArgs *)ctx->multi, n_cs, cs_theta, cs_val, n_hov, hov_node, hov_h,
+    mpcx::AstarIO io{n_search, (const mpcx::AstarArgs *)ctx->multi, n_cs, cs_theta, cs_val, n_ov, ov_key, ov_val,
                      b->heap_cap, b->table_cap, b->log_cap, b->push_cap, b->path_cap, b->heap, b->table, b->log, b->push_log, b->path, b->cost, b->miss,
                      b->status, b->n_exp, b->n_push, b->path_len, b->path_prim};
     hipLaunchKernelGGL(mpcx::astar_kernel, dim3(n_search), dim3(64), 0, ctx->stream, io);

@@ -274,41 +274,56 @@ class Context:
         return out
 
     @_ordered
-    def astar_batch(self, models, specs, cs_theta, cs_val, hov_node=None, hov_h=None, max_expansions=4096, path_cap=64):
+    def astar_batch(self, models, specs, cs_theta, cs_val, ov_key=None, ov_val=None, max_expansions=4096, path_cap=64, heap_cap=None, push_cap=None):
         """mpcx_astar_batch: one device-resident best-first search per entry of `specs` (dicts: start, goal_box, goal_point,
-        allowed_dtheta, variant) against models[i]; cs_theta (ascending) / cs_val: the host's cos / sin table; hov_node / hov_h: the
-        heuristic's override table (nodes sorted as tuples).  Returns a dict of device tensors: status, n_exp, n_push, cost, miss,
-        path_len, path (n, path_cap, 3; goal first), path_prim, log (n, max_expansions, 8), push_log (n, push_cap, 4)."""
+        allowed_dtheta, variant [, wh, wc, hp_norm (device tensor), ov_off, ov_cnt]) against models[i]; cs_theta (ascending) / cs_val: the
+        host's cos / sin table; ov_key (n, 4) / ov_val: the override table, every search's slice sorted as tuples.  Capacities: the log
+        holds max_expansions expansions, the heap `heap_cap` entries and the successor log `push_cap` (default for both: what n_prim
+        successors per expansion can need).  Returns a dict of device tensors: status, n_exp, n_push, cost, miss, path_len, path
+        (n, path_cap, 3; goal first), path_prim, log (n, max_expansions, 8), push_log (n, push_cap, 8)."""
         n = len(specs)
         f, dev = torch.float64, self.device
-        P = models[0].n_prim
-        heap_cap = max(16, P * max_expansions + 1)
+        P = max(m.n_prim for m in models)
+        full = max(16, P * max_expansions + 1)
+        heap_cap = full if heap_cap is None else max(16, min(int(heap_cap), full))
+        push_cap = full if push_cap is None else max(16, min(int(push_cap), full))
         table_cap = 1 << int(np.ceil(np.log2(2 * (max_expansions + 1))))
+        # only the closed set needs a fill (NaN = empty slot); everything else is written by the kernel before anyone reads it
         out = dict(heap=torch.empty((n, heap_cap, 10), dtype=f, device=dev), table=torch.full((n, table_cap, 8), float('nan'), dtype=f, device=dev),
-                   log=torch.zeros((n, max_expansions, 8), dtype=f, device=dev), push_log=torch.zeros((n, heap_cap, 4), dtype=f, device=dev),
-                   path=torch.zeros((n, path_cap, 3), dtype=f, device=dev), path_prim=torch.zeros((n, path_cap), dtype=torch.int32, device=dev),
-                   cost=torch.zeros(n, dtype=f, device=dev), miss=torch.zeros(n, dtype=f, device=dev),
-                   status=torch.zeros(n, dtype=torch.int32, device=dev), n_exp=torch.zeros(n, dtype=torch.int32, device=dev),
-                   n_push=torch.zeros(n, dtype=torch.int32, device=dev), path_len=torch.zeros(n, dtype=torch.int32, device=dev))
+                   log=torch.empty((n, max_expansions, 8), dtype=f, device=dev), push_log=torch.empty((n, push_cap, 8), dtype=f, device=dev),
+                   path=torch.empty((n, path_cap, 3), dtype=f, device=dev), path_prim=torch.empty((n, path_cap), dtype=torch.int32, device=dev),
+                   cost=torch.empty(n, dtype=f, device=dev), miss=torch.zeros(n, dtype=f, device=dev),
+                   status=torch.empty(n, dtype=torch.int32, device=dev), n_exp=torch.empty(n, dtype=torch.int32, device=dev),
+                   n_push=torch.empty(n, dtype=torch.int32, device=dev), path_len=torch.empty(n, dtype=torch.int32, device=dev))
         b = _lib.AstarBuffersC()
-        b.heap_cap, b.table_cap, b.log_cap, b.push_cap, b.path_cap = heap_cap, table_cap, max_expansions, heap_cap, path_cap
+        b.heap_cap, b.table_cap, b.log_cap, b.push_cap, b.path_cap = heap_cap, table_cap, max_expansions, push_cap, path_cap
         for k in ('heap', 'table', 'log', 'push_log', 'path', 'cost', 'miss', 'status', 'n_exp', 'n_push', 'path_len', 'path_prim'):
             setattr(b, k, out[k].data_ptr())
-        sp = (_lib.AstarSearchC * n)()
-        for i, s in enumerate(specs):
-            sp[i].start[:] = [float(v) for v in s['start']]
-            sp[i].goal_box[:] = [float(v) for v in s['goal_box']]
-            sp[i].goal_point[:] = [float(v) for v in s['goal_point']]
-            sp[i].allowed_dtheta = float(s['allowed_dtheta'])
-            sp[i].variant = int(s['variant'])
-            sp[i].max_expansions = int(max_expansions)
+        if isinstance(specs, np.ndarray):       # rows of _lib.ASTAR_SEARCH_DTYPE, filled by the caller (hp_norm: device addresses it keeps alive)
+            if specs.dtype != _lib.ASTAR_SEARCH_DTYPE:
+                raise MpcxError('astar_batch: spec rows must have dtype _lib.ASTAR_SEARCH_DTYPE')
+            rows = np.ascontiguousarray(specs)
+        else:
+            rows = np.zeros(n, dtype=_lib.ASTAR_SEARCH_DTYPE)
+            for i, s in enumerate(specs):
+                r = rows[i]
+                r['start'] = s['start']; r['goal_box'] = s['goal_box']; r['goal_point'] = s['goal_point']
+                r['allowed_dtheta'] = s['allowed_dtheta']
+                r['wh'] = s.get('wh', (1.0, 2.7, 15.0, 0.0, 0.0)); r['wc'] = s.get('wc', (1.0, 5.0, 0.1, 0.0))
+                hn = s.get('hp_norm')
+                if hn is not None:
+                    self._want(hn, f, (models[i].n_rows,), 'hp_norm')
+                    r['hp_norm'] = hn.data_ptr()
+                r['variant'] = s['variant']; r['ov_off'] = s.get('ov_off', 0); r['ov_cnt'] = s.get('ov_cnt', 0)
+        rows['max_expansions'] = int(max_expansions)
+        sp = C.c_void_p(rows.ctypes.data)
         hs = (C.c_void_p * n)(*[m._h for m in models])
         self._want(cs_theta, f, None, 'cs_theta'); self._want(cs_val, f, (cs_theta.shape[0], 2), 'cs_val')
-        n_hov = 0 if hov_node is None else int(hov_node.shape[0])
-        if n_hov:
-            self._want(hov_node, f, (n_hov, 3), 'hov_node'); self._want(hov_h, f, (n_hov,), 'hov_h')
+        n_ov = 0 if ov_key is None else int(ov_key.shape[0])
+        if n_ov:
+            self._want(ov_key, f, (n_ov, 4), 'ov_key'); self._want(ov_val, f, (n_ov,), 'ov_val')
         self._chk(self.lib.mpcx_astar_batch(self._ctx, n, hs, sp, int(cs_theta.shape[0]), _ptr(cs_theta), _ptr(cs_val),
-                                            n_hov, _ptr(hov_node) if n_hov else None, _ptr(hov_h) if n_hov else None, C.byref(b)))
+                                            n_ov, _ptr(ov_key) if n_ov else None, _ptr(ov_val) if n_ov else None, C.byref(b)))
         del out['heap'], out['table']
         return out
 

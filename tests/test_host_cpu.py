@@ -32,6 +32,8 @@ def test_struct_layouts_match_header():
     from mpc_for_av_at_intersection_amd import _lib
     assert ctypes.sizeof(_lib.MpcParamsC) == 8 + 8 * 23 + 8 + 8  # 2 int32 + 23 doubles + (model, reserved) + jerk_weight, no padding surprises
     assert ctypes.sizeof(_lib.InteractionParamsC) == 16 + 8 * 9 + 8 + 8      # + path_cum pointer and its error bound (round 3)
+    assert ctypes.sizeof(_lib.AstarSearchC) == 8 * 20 + 8 + 16 == _lib.ASTAR_SEARCH_DTYPE.itemsize    # 20 doubles, hp_norm, 4 int32 (round 4)
+    assert [_lib.ASTAR_SEARCH_DTYPE.fields[n][1] for n, _ in _lib.AstarSearchC._fields_] == [getattr(_lib.AstarSearchC, n).offset for n, _ in _lib.AstarSearchC._fields_]
     from oracle import oracle_py as orc
     assert ctypes.sizeof(orc._CParams) == ctypes.sizeof(_lib.MpcParamsC)
 
@@ -278,3 +280,48 @@ def test_arc_length_table_error_bound_holds():
             steps = np.append(0.0, np.linalg.norm(pts[1:] - pts[:-1], axis=1))
             worst = max(worst, np.abs((cum[start:b] - cum[start]) - steps.cumsum()).max())
     assert worst <= err, (worst, err)
+
+
+def test_vectorised_reference_expressions_equal_the_scalar_call_surface():
+    """plan_many_device checks every heuristic / edge value the device search used against `_reference_h` / `_reference_edge` (numpy over
+    arrays).  Those must carry the bits of the scalar methods `distance_to_goal` / `neighbor_function` -- the ones the golden runs of the
+    reference pin on the GPU (tests/test_gpu_callsurface.py) -- for every variant with computed terms.  No GPU needed: a stub stands in for
+    the device model."""
+    import numpy as np
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive_search import MotionPrimitiveSearch, _DeviceCheck, _py_square, _POW_WITNESSES
+    from mpc_for_av_at_intersection_amd.lib.scenario import world
+    from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions
+    from mpc_for_av_at_intersection_amd.lib.motion_primitive import load_motion_primitives
+
+    class StubModel:
+        n_prim = 9
+
+    class StubCtx:
+        def search_model(self, *a):
+            return StubModel()
+    # the squares: libm pow, not x * x (and the witnesses really are witnesses on this machine)
+    assert np.array_equal(_py_square(_POW_WITNESSES), np.array([v ** 2 for v in _POW_WITNESSES.tolist()]))
+    assert not np.array_equal(_POW_WITNESSES * _POW_WITNESSES, _py_square(_POW_WITNESSES))
+    cd, mps = BicycleModelDimensions(), load_motion_primitives('bicycle_model')
+    runs = np.load(os.path.join(ROOT, 'tests', 'golden', 'astar_worlds.npz'))
+    rng = np.random.default_rng(0)
+    seen = set()
+    for case in sorted({k.rsplit('/', 1)[0] for k in runs.files}):
+        tag, key = case.split('|')
+        if tag == 'base':
+            continue
+        variant = {'round': 'roundabout', 'single': 'single_lane', 'ml': 'multi_lane'}[tag]
+        kw = dict(wh_obstacle=0.2, wh_center=0.1, wc_center=0.02) if (tag == 'ml' and key.endswith('3_2_1_2_3')) else {}
+        s = MotionPrimitiveSearch(world(key), cd, mps, margin=cd.radius, variant=variant, ctx=StubCtx(), **kw)
+        s._dev_check = _DeviceCheck(s)
+        nodes = runs[case + '/dbg_node']
+        assert np.array_equal(s._reference_h(nodes), np.array([float(s.distance_to_goal(tuple(n))) for n in nodes.tolist()]))
+        children = nodes + rng.normal(0, 1, nodes.shape)
+        kk = rng.integers(0, 9, len(nodes))
+        scalar = []
+        for p, c, k in zip(nodes.tolist(), children.tolist(), kk.tolist()):
+            s._cache = {tuple(p): [(k, tuple(c))]}
+            scalar.append(float(next(iter(s.neighbor_function(tuple(p))))[0]))
+        assert np.array_equal(s._reference_edge(nodes, children, kk), np.array(scalar))
+        seen.add((variant, bool(kw)))
+    assert seen == {('multi_lane', False), ('multi_lane', True), ('roundabout', False), ('single_lane', False)}
