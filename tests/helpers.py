@@ -54,7 +54,7 @@ def ego_resample_dl(n, v0, dt=0.2, max_accel=2.0, max_speed=30.0 / 3.6):
     return dt * max_speed
 
 
-def harvest_closed_loop_qps(ctx, B=4096, A=8, T=20, seed=1000, windows=((3, 6), (100, 6)), hard_iters=10, total=4096, rng_seed=0):
+def harvest_closed_loop_qps(ctx, B=4096, A=8, T=20, seed=1000, windows=((3, 6), (100, 6)), hard_iters=10, total=4096, rng_seed=0, mpc=None):
     """QP inputs out of the benchmark's closed loop (bench.py's workload: synthetic_batch(seed=1000)): for every step of the
     windows [(first step, how many), ...] EVERY problem that took >= hard_iters interior-point iterations, topped up with a random
     sample of the other problems of those steps to `total`.  Inputs are taken as the QP kernel saw them: x0 = column 0 of its state
@@ -62,7 +62,7 @@ def harvest_closed_loop_qps(ctx, B=4096, A=8, T=20, seed=1000, windows=((3, 6), 
     Returns dict of numpy arrays: x0, xref, xbar, re, uw, iters (of the closed-loop solve), step."""
     import torch
     from mpc_for_av_at_intersection_amd.batch import synthetic_batch
-    sim = synthetic_batch(ctx, B=B, A=A, T=T, seed=seed)
+    sim = synthetic_batch(ctx, B=B, A=A, T=T, seed=seed, mpc=mpc)       # mpc: other controller constants (e.g. MpcParams.jerk()); its T wins
     rng = np.random.default_rng(rng_seed)
     hard, rest = [], []
     n_steps = sum(n for _, n in windows)

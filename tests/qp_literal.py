@@ -120,17 +120,20 @@ def kkt_certificate(p, x0, xref, xbar, reaches_end, x, u):
     return dict(eq=eq, ineq=ineq, stat=stat, comp=comp, obj=float(z @ P @ z + q @ z + c0), grad_scale=scale)
 
 
-def exact_solution(p, x0, xref, xbar, reaches_end, z_start, max_rounds=60):
+def exact_solution(p, x0, xref, xbar, reaches_end, z_start, max_rounds=60, add_first=False):
     """The minimiser of the literal problem by an active-set iteration started from the active set of `z_start`: solve the
     equality-constrained KKT system [2P Aeq' Ga'; Aeq 0 0; Ga 0 0] with numpy.linalg.solve, drop the most negative multiplier,
     add violated rows, until multipliers >= 0 and no row is violated -- at which point (z, nu, lam) IS a KKT point of the
     literal problem (strictly convex on the feasible set => the unique optimum, the point ECOS converges to).
     Rows on x[2, 0] (mpc.py:187-188 at t = 0) duplicate the initial-state equality and are left to it.
+    add_first: violated rows enter BEFORE any multiplier may leave (a start far from the optimum, e.g. the empty set, can make the
+    simultaneous rule cycle; the end test -- and therefore the result -- is the same).
     Returns dict(z, active, lam, nu, rounds)."""
     P, q, c0, Aeq, beq, G, h, ix, iu = build(p, x0, xref, xbar, reaches_end)
     n, me = len(q), len(beq)
     skip = set(i for i in range(len(h)) if np.count_nonzero(G[i]) == 1 and abs(G[i][ix(2, 0)]) == 1.0)
     act = set(int(i) for i in np.where(h - G @ z_start < 1e-6)[0] if i not in skip)
+    seen_sets, careful = set(), False
     for rounds in range(max_rounds):
         a = sorted(act)
         Ga, ha, ma = G[a], h[a], len(a)
@@ -147,7 +150,18 @@ def exact_solution(p, x0, xref, xbar, reaches_end, z_start, max_rounds=60):
         if not drop and not add:
             return dict(z=z, active=a, lam=lam, nu=nu, rounds=rounds, slack=slack, obj=float(z @ P @ z + q @ z + c0),
                         eq=float(np.abs(Aeq @ z - beq).max()), stat=float(np.abs(2 * P @ z + q + Aeq.T @ nu + Ga.T @ lam).max()))
-        if drop:
+        key = frozenset(act)
+        if key in seen_sets:
+            careful = True           # the working set came back: from here on ONE row per round (the most violated one first, else the most negative multiplier)
+        seen_sets.add(key)
+        if careful:
+            if add:
+                act.add(min(add, key=lambda i: slack[i]))
+            else:
+                act.discard(min(drop)[1])
+            continue
+        if drop and not (add_first and add):
             act.discard(min(drop)[1])
         act.update(add)
     raise RuntimeError('active-set iteration did not settle')
+
