@@ -227,6 +227,41 @@ def test_expansion_one_million_nodes(ctx):
     print('expand_kernel: 2^20 nodes x %d primitives in %.3f ms = %.1f M nodes/s' % (model.n_prim, ms, n / ms / 1e3))
 
 
+def test_expansion_free_space_frontier_of_the_bench(ctx):
+    """The frontier bench.py's `expand` key times (batch.prius_frontier(free_space=True), 2^20 nodes sampled from free
+    space + the golden Prius expansion logs embedded): every embedded golden node against the reference's flags and successors, a
+    4096-node sample against the oracle, permutation equivariance, and bulk kernel == per-lane kernel on slices (round 3
+    checked the uniform frontier only)."""
+    from mpc_for_av_at_intersection_amd.batch import prius_frontier
+    from oracle import oracle_py as orc
+    ex = H.gold('expand.npz')
+    gold_nodes = ex['pri/nodes']
+    n = 1 << 20
+    model, dev = prius_frontier(ctx, n=n, seed=0, free_space=True, embed=gold_nodes)
+    nodes = dev.cpu().numpy()
+    tables = H.search_tables('prius', 'int_2_1')
+    om = orc.SearchModel(*tables)
+    out = ctx.expand(model, dev)
+    ctx.synchronize()
+    col, nbr, cost = out['collide'].cpu().numpy(), out['nbr'].cpu().numpy(), out['cost'].cpu().numpy()
+    assert np.array_equal(col[:len(gold_nodes)], ex['pri/collide'])             # the reference's flags on its own nodes
+    assert np.abs(nbr[:len(gold_nodes)] - ex['pri/nbr']).max() < 1e-12
+    rng = np.random.default_rng(1)
+    idx = rng.choice(n, 4096, replace=False)
+    onbr, ocol = orc.expand(om, nodes[idx], host_trig=False)
+    assert np.array_equal(ocol, col[idx]) and np.abs(onbr - nbr[idx]).max() < 1e-12
+    free = 1.0 - col[len(gold_nodes):].mean()
+    assert 0.7 < free < 0.95, free                                               # free-space poses: most records survive (uniform frontier: 40 %)
+    perm = rng.permutation(n)
+    out_p = ctx.expand(model, dev[torch.as_tensor(perm, device=dev.device)].contiguous())
+    assert np.array_equal(col[perm], out_p['collide'].cpu().numpy()) and np.array_equal(nbr[perm], out_p['nbr'].cpu().numpy())
+    for lo in list(range(0, 120000, 6000)) + [n - 4000]:
+        part = ctx.expand(model, dev[lo:lo + 4000].contiguous())
+        assert np.array_equal(part['collide'].cpu().numpy(), col[lo:lo + 4000]) and np.array_equal(part['nbr'].cpu().numpy(), nbr[lo:lo + 4000])
+        assert np.array_equal(part['cost'].cpu().numpy(), cost[lo:lo + 4000])
+    print('free-space frontier: %.1f %% of the records free; golden nodes, oracle sample, permutation and slices identical' % (100 * free))
+
+
 def test_config2_256_independent_instances_closed_loop(ctx):
     """BASELINE configs[1] on the workload SURVEY 8(d) config 2 defines (batch.config2_batch: route uniform over the 12 stock paths,
     arc position uniform, lateral offset N(0, 0.3 m), heading error N(0, 0.05 rad), v ~ U[0, 8.33], seed 0): batch = 256 independent
