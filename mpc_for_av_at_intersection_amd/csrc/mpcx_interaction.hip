@@ -135,9 +135,17 @@ __device__ __forceinline__ void divmod_small(int j, int d, float inv_d, int &quo
 
 __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)[4], int na, const double *pred,
                               int ooff, int nobs, int oskip, const double *rem, const double *rcs, int n,
-                              double (*s_box)[4], unsigned short *s_queue, int lane, double &hx, double &hy) {
+                              double (*s_box)[4], unsigned short *s_queue, int lane, double &hx, double &hy
 #ifdef MPCX_INTER_PROFILE
+                              , unsigned long long *fc_prof = nullptr
+#endif
+                              ) {
+#ifdef MPCX_INTER_PROFILE
+    unsigned long long fc_t = __builtin_amdgcn_s_memtime();
+#define FCSTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && fc_prof) fc_prof[k] += t_ - fc_t; fc_t = t_; } while (0)
     int dbg_queued = 0;      // dev build: candidates that reached a run's queue (returned in hx when there is no conflict)
+#else
+#define FCSTAMP(k) do {} while (0)
 #endif
     const double md = 2.0 * ip.radius;
     const double md2lo = md * md * (1.0 - 1e-12), md2hi = md * md * (1.0 + 1e-12);
@@ -165,8 +173,11 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
         if (j == 0) { s_box[sg][0] = x0 - slack; s_box[sg][1] = x1 + slack; s_box[sg][2] = y0 - slack; s_box[sg][3] = y1 + slack; }
     }
     __syncthreads();
+    FCSTAMP(8);      // run boxes
     const long long NOKEY = 0x7fffffffffffffffLL;
     long long best = NOKEY;
+    long long lbest = NOKEY;                               // this lane's own smallest key and the obstacle disc position it belongs to
+    double lpx = 0.0, lpy = 0.0;
     int sg_limit = NSEG;                                   // runs >= sg_limit cannot hold the first row any more
     const int ncand_all = nobs * steps * 2;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -189,6 +200,7 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
 #pragma unroll
         for (int u = 0; u < 8; u++)
             if (cb + u * WAVE + lane >= ncand_all) { ox[u] = INFINITY; oy[u] = INFINITY; }       // fails every box test
+        FCSTAMP(9);      // candidate loads
         for (int sg = 0; sg < sg_limit; sg++) {             // wave-uniform
             const double b0 = s_box[sg][0], b1 = s_box[sg][1], b2 = s_box[sg][2], b3 = s_box[sg][3];
             int qn = 0;
@@ -199,6 +211,7 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
                 if (in) s_queue[qn + __popcll(m & lt_mask)] = (unsigned short)(u * WAVE + lane);
                 qn += __popcll(m);
             }
+            FCSTAMP(10);     // box tests + compaction of one run
             if (qn == 0) continue;
 #ifdef MPCX_INTER_PROFILE
             dbg_queued += qn;
@@ -227,7 +240,7 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
                                 // key = reference row order (frame, agent disc, obstacle, offset, obstacle disc); offsets ascend =>
                                 // obstacle frames descend; the first offset reaching g is the one that counts
                                 const long long key = ((((long long)f * 2 + ca) * MPCX_MAX_OBS + o) * MPCX_PRED_STEPS_MAX + (steps - 1 - g)) * 2 + co;
-                                best = key < best ? key : best;
+                                if (key < lbest) { lbest = key; lpx = px; lpy = py; }
                                 found = true;
                             }
                         }
@@ -235,45 +248,50 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
                 }
             }
             __syncthreads();                               // the queue is rewritten by the next run
+            FCSTAMP(11);     // queue work of one run
             if (__ballot(found)) {                         // rows of later runs come later in the reference's order
-                best = wave_min_ll(best);
                 sg_limit = sg + 1;                         // later chunks: only runs up to this one can still win
                 break;
             }
         }
     }
-    best = wave_min_ll(best);
+    best = wave_min_ll(lbest);
 #ifdef MPCX_INTER_PROFILE
     if (best == NOKEY) hx = (double)dbg_queued;
 #endif
     if (best == NOKEY) return -1;
-    // decode the obstacle disc of the first row
-    const int co = (int)(best & 1);
-    const int g = steps - 1 - (int)((best >> 1) % MPCX_PRED_STEPS_MAX);
-    const int o = (int)(((best >> 1) / MPCX_PRED_STEPS_MAX) % MPCX_MAX_OBS);
-    int pool = ooff + o;
-    if (oskip >= 0 && pool >= oskip) pool += 1;
-    const double ox = pred[((size_t)pool * steps + g) * 4 + 2 * co], oy = pred[((size_t)pool * steps + g) * 4 + 2 * co + 1];
+    // the obstacle disc of the first row: the lane that found the key still holds its position (a key belongs to one candidate, a
+    // candidate to one lane) -- no decode, no load
+    const int owner = (int)__ffsll((long long)__ballot(lbest == best)) - 1;
+    const double ox = rdlane(lpx, owner), oy = rdlane(lpy, owner);
 
     // ---- collision_avoidance.py:88-104: earliest pose of the detailed path (front-disc block, then rear-disc block)
     // The answer is the smallest index of the front-disc block if that block has a hit at all, else the smallest of the
     // rear-disc block: each block is walked in index order, 64 poses at a time, and left at the first batch with a hit.
     int first = 0x7fffffff;
+    constexpr int PD = 4;      // batches of 64 poses in flight: the scan leaves at its first hit, and one batch per memory round trip made it a chain of 2-5
     for (int d = 0; d < 2 && first == 0x7fffffff; d++) {
         const double cx = ip.circle_centers[2 * d], cy = ip.circle_centers[2 * d + 1];
-        for (int i0 = 0; i0 < n; i0 += WAVE) {
-            const int i = i0 + lane;
-            bool hit = false;
-            if (i < n) {
-                const double px = rem[3 * i], py = rem[3 * i + 1], c = rcs[2 * i], s = rcs[2 * i + 1];
-                const double ex = __dadd_rn(__dadd_rn(__dmul_rn(c, cx), -__dmul_rn(s, cy)), px);
-                const double ey = __dadd_rn(__dadd_rn(__dmul_rn(s, cx), __dmul_rn(c, cy)), py);
-                hit = within(ox, oy, ex, ey, md, md2lo, md2hi);
+        for (int i0 = 0; i0 < n && first == 0x7fffffff; i0 += PD * WAVE) {
+            double px[PD], py[PD], pc[PD], ps[PD];
+#pragma unroll
+            for (int k = 0; k < PD; k++) {
+                const int i = i0 + k * WAVE + lane;
+                const int ic = i < n ? i : n - 1;             // clamped address, masked below
+                px[k] = rem[3 * ic]; py[k] = rem[3 * ic + 1]; pc[k] = rcs[2 * ic]; ps[k] = rcs[2 * ic + 1];
             }
-            const unsigned long long m = __ballot(hit);
-            if (m) { first = d * n + i0 + (int)__ffsll((long long)m) - 1; break; }      // wave-uniform
+#pragma unroll
+            for (int k = 0; k < PD; k++) {
+                const int i = i0 + k * WAVE + lane;
+                const double ex = __dadd_rn(__dadd_rn(__dmul_rn(pc[k], cx), -__dmul_rn(ps[k], cy)), px[k]);
+                const double ey = __dadd_rn(__dadd_rn(__dmul_rn(ps[k], cx), __dmul_rn(pc[k], cy)), py[k]);
+                const bool hit = i < n && within(ox, oy, ex, ey, md, md2lo, md2hi);
+                const unsigned long long m = __ballot(hit);
+                if (m && first == 0x7fffffff) first = d * n + i0 + k * WAVE + (int)__ffsll((long long)m) - 1;      // wave-uniform
+            }
         }
     }
+    FCSTAMP(12);     // earliest pose
     first = (first == 0x7fffffff) ? 0 : first % n;      // argmax of an all-False mask is 0
     hx = rem[3 * first]; hy = rem[3 * first + 1];
     return first;
@@ -282,7 +300,7 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
 constexpr int MAXF_STATIC = MPCX_EGO_FRAMES_MAX;      // moving_collision_kernel (explicit trajectories)
 
 #ifdef MPCX_INTER_PROFILE
-#define ISTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) ((unsigned long long *)(a.hit_xy + 2 * (size_t)a.P))[8 * (size_t)p + (k)] = t_ - t_last; t_last = t_; } while (0)   /* dev build: needs 8 slots per ego behind hit_xy */
+#define ISTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) ((unsigned long long *)(a.hit_xy + 2 * (size_t)a.P))[16 * (size_t)p + (k)] = t_ - t_last; t_last = t_; } while (0)   /* dev build: needs 16 slots per ego behind hit_xy */
 #else
 #define ISTAMP(k) do {} while (0)
 #endif
@@ -320,13 +338,27 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
             a.keyslot[p] = (k << 24) | atomicAdd(&a.bin_cnt[(p % MPCX_ORDER_COPIES) * MPCX_ORDER_BINS + k], 1);
         }
     };
-    if (pcut > 0) {
-        const int last = pcut - 1;
-        advance = (path[3 * tidx] != path[3 * last]) || (path[3 * tidx + 1] != path[3 * last + 1]) ||
-                  (path[3 * tidx + 2] != path[3 * last + 2]);
-    }
     const int t_old = tidx;
     const int n_old = len - t_old;
+    // The first batches of the distance pass are requested BEFORE it is known whether the ego advances at all (their addresses need only the
+    // path and the old index): they travel together with the six values of the test below instead of one memory round trip later.  The
+    // test itself loads all six values and compares them without short-circuit branches -- (a != b) || (c != d) || ... is a chain of up
+    // to three dependent round trips for exactly the egos that stand still.
+    constexpr int DEPTH = 4;
+    double bx[DEPTH], by[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) {
+        const int i = k * WAVE + lane;
+        const double *q = path + 3 * (size_t)(t_old + ((i < n_old && n_old <= MAXREM) ? i : 0));       // clamped address, selected afterwards
+        const double vx = q[0], vy = q[1];
+        bx[k] = i < n_old ? vx : 0.0; by[k] = i < n_old ? vy : 0.0;
+    }
+    {
+        const int last = pcut > 0 ? pcut - 1 : tidx;
+        const double ax = path[3 * tidx], ay = path[3 * tidx + 1], ath = path[3 * tidx + 2];
+        const double lx = path[3 * last], ly = path[3 * last + 1], lth = path[3 * last + 2];
+        advance = (pcut <= 0) | (ax != lx) | (ay != ly) | (ath != lth);
+    }
     const int nobs = a.obs_cnt[p] - ((a.obs_skip && a.obs_skip[p] >= 0) ? 1 : 0);
     if (n_old > MAXREM || nobs > MPCX_MAX_OBS) {
         if (lane == 0) { a.hit_idx[p] = -2; a.cut_len[p] = len; file_key(len); a.hit_xy[2 * p] = 0; a.hit_xy[2 * p + 1] = 0; }
@@ -346,15 +378,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     if (!tab || advance) {
         // the points arrive in batches of DEPTH x 64: the loads of the next batch are all in flight while this one is worked on (one
         // batch deep the pass waited for an L2 round trip per 64 points: it is bound by its loads, not by its arithmetic)
-        constexpr int DEPTH = 4;
-        double bx[DEPTH], by[DEPTH], lastx = 0.0, lasty = 0.0;
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) {
-            const int i = k * WAVE + lane;
-            const double *q = path + 3 * (size_t)(t_old + (i < n_old ? i : 0));       // clamped address, selected afterwards
-            const double vx = q[0], vy = q[1];
-            bx[k] = i < n_old ? vx : 0.0; by[k] = i < n_old ? vy : 0.0;
-        }
+        double lastx = 0.0, lasty = 0.0;
         for (int i0 = 0; i0 < n_old; i0 += DEPTH * WAVE) {
             double nbx[DEPTH], nby[DEPTH];
 #pragma unroll
@@ -529,19 +553,120 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
         }
         return base;
     };
-    if (tab) {      // running sums from the table, four batches of loads in flight (one by one the pass waited a memory round trip per 64 points)
-        for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
-            double t[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const int i = i0 + k * WAVE + lane; t[k] = cumtab[tidx + (i < n ? i : 0)]; }
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const int i = i0 + k * WAVE + lane; if (i < n) s_cum[shift + i] = t[k] - cum0; }
+    // Round 4: the kept poses by SEARCH instead of a scan.  Beyond the first 64 points dl is a constant (the predicted speed has saturated), so
+    // the buckets floor(c_i / dl) never decrease along the path and the kept points -- those whose bucket exceeds their predecessor's -- are
+    // the FIRST point of every bucket value that occurs: one binary search in the arc-length table per bucket boundary (~36 of them, one per
+    // lane) instead of a pass over all ~700 points (which was a third of this kernel's instructions), and the table no longer goes through
+    // LDS.  The margin test that guards the fast sums is only needed where it can fail: at the two points around every boundary and at
+    // the last point (a quotient close to an integer m elsewhere would put a boundary point at least as close to m).  First 64 points: as
+    // before, point by point (dl varies there while the ego accelerates).  Same kept set as the scan, bit for bit (tests + the
+    // MPCX_INTER_FORCE_EXACT build, which still takes the sequential path).
+    const bool search_ok = tab && n > WAVE &&
+                           (!accel_phase || (ip.max_accel >= 0.0 && !(__dadd_rn(__dmul_rn(ip.max_accel, (double)(WAVE + 1)), v) < ip.max_speed)));
+    auto resample_search = [&](bool &unsure) -> int {
+        const double *ct = cumtab + tidx;
+        auto risky = [&](double c, double r, double dl_, double inv_) -> bool {
+            return c != 0.0 && (!(dl_ > 0.0) || !(r < 4e15) || !(fabs(r - rint(r)) > marg * inv_ + 2e-15 * fabs(r)));
+        };
+        unsure = false;
+        // ---- points 0..63 (n > 64: none of them is the last point)
+        double dl = dl_const, inv = inv_const;
+        if (accel_phase && (!(ip.max_accel >= 0.0) || __dadd_rn(__dmul_rn(ip.max_accel, 1.0), v) < ip.max_speed)) {
+            const double r = __dadd_rn(__dmul_rn(ip.max_accel, (double)(lane + 1)), v);
+            dl = __dmul_rn(ip.dt, fmin(r, ip.max_speed));
+            inv = frcp(dl);
         }
-    } else prefix_fast();
-    __syncthreads();
-    ISTAMP(2);      // cumulative lengths
+        const double c0 = ct[lane] - cum0;
+        const double r0 = c0 * inv;
+        const double qd = floor(r0);
+        if (risky(c0, r0, dl, inv)) unsure = true;
+        const double qprev = lane_prev(qd, 0.0);
+        const bool keep0 = (lane == 0) || (qd - qprev >= 1.0);
+        const unsigned long long m0 = __ballot(keep0);
+        {
+            const int pos = __popcll(m0 & ((1ull << lane) - 1ull));
+            if (keep0 && pos < MAXF) s_keep[pos] = lane;
+        }
+        int base = __popcll(m0);
+        const double Q63 = rdlane(qd, WAVE - 1);
+        // ---- point 64 (the first with the constant dl) and the last point
+        const double c64 = ct[WAVE] - cum0, cl = ct[n - 1] - cum0;
+        const double r64 = c64 * inv_const, rl = cl * inv_const;
+        const double Q64 = floor(r64), Ql = floor(rl);
+        if (risky(c64, r64, dl_const, inv_const) || risky(cl, rl, dl_const, inv_const)) unsure = true;
+        if (__ballot(unsure)) return base;                    // (wave-uniform) the caller redoes the ego with the sequential sums
+        if ((Q64 - Q63 >= 1.0) || n - 1 == WAVE) {
+            if (lane == 0 && base < MAXF) s_keep[base] = WAVE;
+            base++;
+        }
+        // ---- one target bucket value per lane: idx(b) = first i in [65, n) with floor(c_i / dl) >= b, b = Q64 + 1 .. Ql
+        const int ntar = (int)(Ql - Q64);                     // 0 <= ntar: the buckets do not decrease; < 4e15 checked above
+        int last_idx = WAVE;                                  // the largest index handled so far
+        if (ntar > 0) {
+            int span = n - 1 - (WAVE + 1), iters = 0;         // search range [65, n - 1]: r_{n-1} >= Ql >= b, so the answer exists
+            while (span > 0) { iters++; span >>= 1; }
+            // planner paths are sampled at (nearly) equal arc-length steps, so the boundary is where a straight line through c_64 and
+            // c_{n-1} puts it: ONE probe of the two points around the guess -- they are the two points the margin test needs anyway --
+            // instead of a chain of ~10 dependent loads; the binary search remains for a path on which the guess misses
+            const double hstep = (cl - c64) / (double)(n - 1 - WAVE);
+            const double inv_h = hstep > 0.0 ? 1.0 / hstep : 0.0;
+            for (int t0 = 0; t0 < ntar; t0 += WAVE) {
+                const int t = t0 + lane;
+                const bool valid = t < ntar;
+                const double b = valid ? Q64 + 1.0 + (double)t : Ql;
+                double gd = ceil((b * dl_const - c64) * inv_h) + (double)WAVE;
+                gd = fmin(fmax(gd, (double)(WAVE + 1)), (double)(n - 1));
+                int idx = (int)gd;
+                double cj = ct[idx] - cum0, ci = ct[idx - 1] - cum0;
+                const bool miss = valid && !((ci * inv_const < b) && (cj * inv_const >= b));
+                if (__ballot(miss)) {                         // wave-uniform
+                    int lo = miss ? WAVE + 1 : idx, hi = miss ? n - 1 : idx;
+                    for (int it = 0; it < iters; it++) {      // uniform trip count; a lane that has converged repeats its last probe
+                        const int mid = lo < hi ? (lo + hi) >> 1 : lo;
+                        const double cm = ct[mid] - cum0;
+                        const bool ge = cm * inv_const >= b;
+                        if (lo < hi) { if (ge) hi = mid; else lo = mid + 1; }
+                    }
+                    idx = lo;
+                    cj = ct[idx] - cum0; ci = ct[idx - 1] - cum0;
+                }
+                if (valid && (risky(cj, cj * inv_const, dl_const, inv_const) || risky(ci, ci * inv_const, dl_const, inv_const))) unsure = true;
+                int prev = __shfl_up(idx, 1, WAVE);
+                if (lane == 0) prev = last_idx;
+                const bool isnew = valid && idx != prev;
+                const unsigned long long mk = __ballot(isnew);
+                const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
+                if (isnew && pos < MAXF) s_keep[pos] = idx;
+                base += __popcll(mk);
+                const int nv = ntar - t0 < WAVE ? ntar - t0 : WAVE;
+                last_idx = __shfl(idx, nv - 1, WAVE);
+            }
+        }
+        if (n - 1 > WAVE && last_idx != n - 1) {              // keep_last_point
+            if (lane == 0 && base < MAXF) s_keep[base] = n - 1;
+            base++;
+        }
+        return base;
+    };
     bool unsure;
-    int na = resample(std::true_type{}, unsure);
+    int na;
+    if (search_ok) {
+        ISTAMP(2);
+        na = resample_search(unsure);
+    } else {
+        if (tab) {      // running sums from the table, four batches of loads in flight (one by one the pass waited a memory round trip per 64 points)
+            for (int i0 = 0; i0 < n; i0 += 4 * WAVE) {
+                double t[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int i = i0 + k * WAVE + lane; t[k] = cumtab[tidx + (i < n ? i : 0)]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int i = i0 + k * WAVE + lane; if (i < n) s_cum[shift + i] = t[k] - cum0; }
+            }
+        } else prefix_fast();
+        __syncthreads();
+        ISTAMP(2);      // cumulative lengths
+        na = resample(std::true_type{}, unsure);
+    }
 #ifdef MPCX_INTER_FORCE_EXACT
     unsure = true;                            // dev build: every ego takes the sequential path (tests run both builds)
 #endif
@@ -571,7 +696,12 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     ISTAMP(4);      // ego discs
     const int ooff = a.obs_off[p], oskip = a.obs_skip ? a.obs_skip[p] : -1;
     double hx, hy;
+#ifdef MPCX_INTER_PROFILE
+    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, s_queue, lane, hx, hy,
+                                     (unsigned long long *)(a.hit_xy + 2 * (size_t)a.P) + 16 * (size_t)p);
+#else
     const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, s_queue, lane, hx, hy);
+#endif
     ISTAMP(5);      // conflict search (+ path scan on a hit)
     if (first < 0) {
 #ifdef MPCX_INTER_PROFILE

@@ -212,6 +212,40 @@ def test_arc_length_table_changes_nothing(ctx):
         assert (outs[0][1] >= 0).any() and (outs[0][1] == -1).any()          # conflicts and free agents both occur
 
 
+def test_resampling_by_search_on_unevenly_sampled_paths(ctx):
+    """Round 4: with the arc-length table the kept poses of `resample_curve` (trajectories.py:58-86) come from one probe per bucket boundary
+    at the index a straight line through the table predicts, and from a binary search where that misses.  Planner paths are evenly
+    sampled (the guess always hits); here two thirds of the path points are dropped at random, so steps of 1 .. 8 spacings alternate and
+    the guess misses most of the time: same integer outputs as the point-by-point scan without the table and as the sequential fallback."""
+    import dataclasses
+    from mpc_for_av_at_intersection_amd.batch import stock_routes, synthetic_batch
+    routes, dl, cd = stock_routes(ctx)
+    rng = np.random.default_rng(11)
+    thin = []
+    for r in routes:
+        keep = np.sort(np.concatenate([[0, len(r) - 1], rng.choice(np.arange(1, len(r) - 1), (len(r) - 2) // 3, replace=False)]))
+        thin.append(np.ascontiguousarray(r[keep]))
+    sim = synthetic_batch(ctx, B=64, A=8, T=20, seed=7, routes=thin, dl=dl, cd=cd)
+    assert sim.ip.path_cum is not None
+    seen_conflict = False
+    for burn in (2, 12, 25):
+        sim.run(burn)
+        ctx.synchronize()
+        outs = []
+        for ip in (dataclasses.replace(sim.ip, path_cum=None), sim.ip, dataclasses.replace(sim.ip, path_cum_err=1.0)):
+            tr = sim.traj_idx.clone()
+            o = ctx.interaction(ip, sim.state, sim.path, sim.path_cs, sim.path_off, sim.path_len, sim.inter['cut_len'].clone(), sim.obs6,
+                                sim.obs_off, sim.obs_cnt, sim.obs_skip, tr)
+            ctx.synchronize()
+            outs.append((tr.cpu().numpy(), o['hit_idx'].cpu().numpy(), o['cut_len'].cpu().numpy(), o['hit_xy'].cpu().numpy()))
+        for other in outs[1:]:
+            for x, y in zip(outs[0], other):
+                assert np.array_equal(x, y)
+        assert (outs[0][1] > -2).all()                                       # nobody beyond the kernel's capacity
+        seen_conflict |= bool((outs[0][1] >= 0).any())
+    assert seen_conflict
+
+
 @pytest.mark.parametrize('n_prim,n_obst,pts', [(5, 40, 20), (16, 70, 9), (1, 3, 40), (9, 24, 14)])
 def test_bulk_expansion_equals_per_lane_and_oracle_on_synthetic_models(ctx, n_prim, n_obst, pts):
     """The bulk expansion kernel (>= 4096 nodes: pairs of a wavefront worked off together, record boxes from the template's box, obstacle boxes
