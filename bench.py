@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix rate (datasheet; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md chip table
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_final.csv')
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_final.csv")
 
 
 def qp_flops_condensed(T: int, iters: float, extra_passes: float = 0.0) -> float:
