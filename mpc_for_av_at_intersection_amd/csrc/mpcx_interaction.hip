@@ -180,7 +180,6 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
     double lpx = 0.0, lpy = 0.0;
     int sg_limit = NSEG;                                   // runs >= sg_limit cannot hold the first row any more
     const int ncand_all = nobs * steps * 2;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int cb = 0; cb < ncand_all; cb += 8 * WAVE) {
         double ox[8], oy[8];
         // all eight loads of the lane in flight at once, from addresses that are valid for every lane (clamped); out-of-range
@@ -203,37 +202,41 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
         FCSTAMP(9);      // candidate loads
         for (int sg = 0; sg < sg_limit; sg++) {             // wave-uniform
             const double b0 = s_box[sg][0], b1 = s_box[sg][1], b2 = s_box[sg][2], b3 = s_box[sg][3];
-            int qn = 0;
+            // Round 4: no queue.  Which of the lane's eight positions lie in the run's box is a bit mask, and every lane works its OWN set bits
+            // off, one per pass (consecutive candidates -- the frames and discs of one obstacle -- sit on consecutive lanes, so the positions
+            // inside a box are spread over the lanes: one or two passes).  The compaction into an LDS queue cost a ballot, two pop counts
+            // and a store per position and run, two barriers per run, and a RELOAD of every queued position (one more memory round trip per
+            // run visited, in a kernel whose time is a chain of such round trips).
+            unsigned mask = 0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const bool in = (ox[u] >= b0) && (ox[u] <= b1) && (oy[u] >= b2) && (oy[u] <= b3);
-                const unsigned long long m = __ballot(in);
-                if (in) s_queue[qn + __popcll(m & lt_mask)] = (unsigned short)(u * WAVE + lane);
-                qn += __popcll(m);
-            }
-            FCSTAMP(10);     // box tests + compaction of one run
-            if (qn == 0) continue;
+            for (int u = 0; u < 8; u++)
+                mask |= (unsigned)((ox[u] >= b0) & (ox[u] <= b1) & (oy[u] >= b2) & (oy[u] <= b3)) << u;
+            FCSTAMP(10);     // box tests of one run
 #ifdef MPCX_INTER_PROFILE
-            dbg_queued += qn;
+            dbg_queued += (int)wave_sum((double)__popc(mask));
 #endif
-            __syncthreads();
-            const int f0 = sg * SL, f1 = (sg + 1) * SL < F ? (sg + 1) * SL : F;
+            if (!__ballot(mask != 0u)) continue;
+            const int f0 = sg * SL;
+            int f1 = (sg + 1) * SL < F ? (sg + 1) * SL : F;
             bool found = false;
-            for (int it0 = 0; it0 < qn; it0 += WAVE) {
-                const int it = it0 + lane;
-                if (it < qn) {
-                    const int cidx = cb + (int)s_queue[it];
-                    const int co = cidx & 1;
-                    int g, o;
-                    divmod_small(cidx >> 1, steps, inv_steps, o, g);
-                    int pool = ooff + o;
-                    if (oskip >= 0 && pool >= oskip) pool += 1;
-                    const double *qq = pred + ((size_t)pool * steps + g) * 4 + 2 * co;
-                    const double px = qq[0], py = qq[1];
-                    for (int f = f0; f < f1; f++) {
-                        const int ff = f < steps ? f : steps - 1;
-                        if (abs(g - ff) > w) continue;       // no offset d in [-w, w] maps padded frame ff onto obstacle frame g
-                        const int fe = f < na ? f : na - 1;
+            while (__ballot(mask != 0u)) {                  // wave-uniform: as many passes as the busiest lane has positions in the box
+                const bool on = mask != 0u;
+                const int u = on ? __ffs((int)mask) - 1 : 0;
+                mask &= mask - 1;
+                double px = ox[0], py = oy[0];
+#pragma unroll
+                for (int q = 1; q < 8; q++) { px = (u == q) ? ox[q] : px; py = (u == q) ? oy[q] : py; }
+                const int cidx = cb + u * WAVE + lane;
+                const int co = cidx & 1;
+                int g, o;
+                divmod_small(cidx >> 1, steps, inv_steps, o, g);
+                // frame-major, all lanes on the same frame: the key is ordered by the frame first, so once ANY lane has a hit at frame f no
+                // later frame can hold the first row -- this pass ends with frame f, and later passes need not look beyond it
+                for (int f = f0; f < f1; f++) {             // wave-uniform bounds
+                    const int ff = f < steps ? f : steps - 1;
+                    const int fe = f < na ? f : na - 1;
+                    bool hit = false;
+                    if (on && abs(g - ff) <= w) {            // else: no offset d in [-w, w] maps padded frame ff onto obstacle frame g
 #pragma unroll
                         for (int ca = 0; ca < 2; ca++) {
                             if (within(s_ego[fe][2 * ca], s_ego[fe][2 * ca + 1], px, py, md, md2lo, md2hi)) {
@@ -241,14 +244,14 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
                                 // obstacle frames descend; the first offset reaching g is the one that counts
                                 const long long key = ((((long long)f * 2 + ca) * MPCX_MAX_OBS + o) * MPCX_PRED_STEPS_MAX + (steps - 1 - g)) * 2 + co;
                                 if (key < lbest) { lbest = key; lpx = px; lpy = py; }
-                                found = true;
+                                hit = true;
                             }
                         }
                     }
+                    if (__ballot(hit)) { found = true; f1 = f + 1; break; }
                 }
             }
-            __syncthreads();                               // the queue is rewritten by the next run
-            FCSTAMP(11);     // queue work of one run
+            FCSTAMP(11);     // distance tests of one run
             if (__ballot(found)) {                         // rows of later runs come later in the reference's order
                 sg_limit = sg + 1;                         // later chunks: only runs up to this one can still win
                 break;
