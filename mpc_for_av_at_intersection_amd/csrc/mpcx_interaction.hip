@@ -135,7 +135,7 @@ __device__ __forceinline__ void divmod_small(int j, int d, float inv_d, int &quo
 
 __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)[4], int na, const double *pred,
                               int ooff, int nobs, int oskip, const double *rem, const double *rcs, int n,
-                              double (*s_box)[4], unsigned short *s_queue, int lane, double &hx, double &hy
+                              double (*s_box)[4], int lane, double &hx, double &hy
 #ifdef MPCX_INTER_PROFILE
                               , unsigned long long *fc_prof = nullptr
 #endif
@@ -311,14 +311,15 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     // dynamic LDS, sized by the host from the longest path of the call (mpcx_interaction_params.max_path_len):
     //   s_cum [max_rem] doubles   step / cumulative lengths of the remaining path; once the resampling has consumed them the
     //                             same bytes hold s_ego [fcap][4] (ego disc centres per kept pose) and the candidate queue
-    //   s_keep [fcap] ints        indices of the kept poses
+    //   s_keep [fcap] shorts      indices of the kept poses
+    // (round 4: no static LDS, 16-bit indices, no candidate queue: 6464 B at the benchmark's capacity.  Six wavefronts per SIMD -- launch bound 6: 80 VGPRs, 64 B/lane of
+    // scratch -- measured 0.138 ms against 0.122 at five: the kernel is bound by instruction issue, more wavefronts only share it)
     extern __shared__ double s_dyn[];
     const int MAXREM = a.max_rem, MAXF = a.fcap;
     double *s_cum = s_dyn;
-    int *s_keep = reinterpret_cast<int *>(s_dyn + MAXREM);
+    unsigned short *s_keep = reinterpret_cast<unsigned short *>(s_dyn + MAXREM);             // (indices < max_rem <= 4096)
     double (*s_ego)[4] = reinterpret_cast<double (*)[4]>(s_cum);
-    unsigned short *s_queue = reinterpret_cast<unsigned short *>(s_cum + (size_t)MAXF * 4);   // candidate queue of first_conflict
-    __shared__ double s_box[NSEG][4];     // bounding boxes of the ego discs per run of frames
+    double (*s_box)[4] = reinterpret_cast<double (*)[4]>(s_cum + (size_t)MAXF * 4);           // bounding boxes of the ego discs per run of frames (256 B behind s_ego)
 
     const int p = blockIdx.x, lane = threadIdx.x;
 #ifdef MPCX_INTER_PROFILE
@@ -700,10 +701,10 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     const int ooff = a.obs_off[p], oskip = a.obs_skip ? a.obs_skip[p] : -1;
     double hx, hy;
 #ifdef MPCX_INTER_PROFILE
-    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, s_queue, lane, hx, hy,
+    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, lane, hx, hy,
                                      (unsigned long long *)(a.hit_xy + 2 * (size_t)a.P) + 16 * (size_t)p);
 #else
-    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, s_queue, lane, hx, hy);
+    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, lane, hx, hy);
 #endif
     ISTAMP(5);      // conflict search (+ path scan on a hit)
     if (first < 0) {
@@ -768,7 +769,6 @@ __global__ __launch_bounds__(64) void moving_collision_kernel(MovArgs a) {
     constexpr int MAXF = MAXF_STATIC;
     __shared__ double s_ego[MAXF][4];
     __shared__ double s_box[NSEG][4];
-    __shared__ unsigned short s_queue[QCAP];
     const int p = blockIdx.x, lane = threadIdx.x;
     const mpcx_interaction_params &ip = a.ip;
     const int na = a.ego_len[p], n = a.path_len[p], nobs = a.obs_cnt[p];
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(64) void moving_collision_kernel(MovArgs a) {
     __syncthreads();
     double hx, hy;
     const int first = first_conflict(ip, s_ego, na, a.pred, a.obs_off[p], nobs, -1,
-                                     a.path + 3 * (size_t)a.path_off[p], a.path_cs + 2 * (size_t)a.path_off[p], n, s_box, s_queue, lane, hx, hy);
+                                     a.path + 3 * (size_t)a.path_off[p], a.path_cs + 2 * (size_t)a.path_off[p], n, s_box, lane, hx, hy);
     if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = first < 0 ? 0.0 : hx; a.hit_xy[2 * p + 1] = first < 0 ? 0.0 : hy; }
 }
 
@@ -823,7 +823,7 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
     if (max_rem > MPCX_MAX_PATH_LEN)
         return mpcx_fail(ctx, MPCX_E_INVALID, "interaction_batch: max_path_len %d exceeds %d", ip->max_path_len, MPCX_MAX_PATH_LEN);
     const int fcap = max_rem / 4 - mpcx::QCAP * 2 / 32;
-    const size_t lds = (size_t)max_rem * sizeof(double) + (size_t)fcap * sizeof(int);
+    const size_t lds = (size_t)max_rem * sizeof(double) + ((size_t)fcap * sizeof(unsigned short) + 7) / 8 * 8;
     mpcx::InterArgs ia{*ip, P, state, path_xyyaw, path_cs, path_off, path_len, prev_cut_len, ctx->pred,
                        obs_off, obs_cnt, obs_skip, traj_idx, hit_idx, hit_xy, cut_len, max_rem, fcap, ctx->inter_prev_save,
                        ctx->bin_hint, ctx->bin_hint ? ctx->bins : nullptr, ctx->bin_hint ? ctx->bins + MPCX_ORDER_COPIES * MPCX_ORDER_BINS : nullptr};
