@@ -237,7 +237,7 @@ def main():
         qp ms per launch, launches, max iterations).  Iterations / failures come from the library's device-side run statistics
         (mpcx_closed_loop_stats) or, for the staged rehearsal exchange, from torch reductions."""
         staged = callable(sim.exchange)
-        ctx.profile_qp(True); ctx.profile_qp_read()
+        ctx.profile_qp(not os.environ.get('MPCX_BENCH_NO_QP_EVENTS')); ctx.profile_qp_read()      # (dev aid: what the event pairs around every QP launch cost the timed region)
         ctx.closed_loop_stats(reset=True)
         iters_sum.zero_(); fail_sum.zero_()
         barrier()
@@ -289,6 +289,7 @@ def main():
     extra_passes = 1.0 + 1.07 * (1.0 - trial_frac)
     flops_survey = qp_flops_condensed(T, mean_iters)                      # SURVEY 8(d)'s formula as written
     flops_qp = qp_flops_condensed(T, mean_iters, extra_passes)           # + the trial / polish passes
+    qp_ms = qp_ms if qp_ms > 0 else float('nan')        # (dev aid MPCX_BENCH_NO_QP_EVENTS: no kernel time)
     achieved_tf = flops_qp * P_rank / (qp_ms * 1e-3) / 1e12
     survey_tf = flops_survey * P_rank / (qp_ms * 1e-3) / 1e12
     own_tf = (qp_flops_stage(T, mean_iters) if stage else flops_qp) * P_rank / (qp_ms * 1e-3) / 1e12

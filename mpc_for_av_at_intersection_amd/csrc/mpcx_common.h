@@ -36,6 +36,11 @@ struct mpcx_ctx {
     bool bin_reset = false;               // set around the plant step: zero bins and ticket
     const double *pack_state = nullptr, *pack_applied = nullptr;   // mpcx_closed_loop_run, local pool: the prediction kernel packs the pool rows itself
     int32_t *inter_prev_save = nullptr;   // mpcx_closed_loop_run: where the conflict search leaves the cut lengths it read (the queue order's `moved` test)
+    // mpcx_closed_loop_run: the conflict search and the window selection both run calc_nearest_index_in_direction for the same agent, state
+    // and path, mostly from the same start index.  The conflict search leaves (its start index, the largest of its three nearest indices
+    // or -1) per agent here (behind prev_cut), and the window selection takes the conflict search's answer where that is provably its own.
+    int32_t *inter_near = nullptr;        // set around the conflict search (2 ints per agent) ...
+    const int32_t *window_near = nullptr, *window_tidx = nullptr;   // ... and around the window selection (+ the conflict search's updated traj_idx)
     hipStream_t side = nullptr; // side stream of mpcx_mpc_prepare_batch: the warm-start rollout runs beside the window selection (fork / join by events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool rollout_forked = false; // mpcx_closed_loop_run has the rollout of this step in flight on the side stream (mpcx_rollout_fork)

@@ -76,6 +76,7 @@ struct InterArgs {
     int32_t *prev_save;   // optional: the previous cut length as read (cut_len may alias prev_cut and is overwritten)
     const int32_t *bin_hint;   // optional (closed loop): file the agent under its work-queue key: bin_cnt[p % COPIES][key]++ -> slot, keyslot[p] = key << 24 | slot
     int32_t *bin_cnt, *keyslot;
+    int32_t *near;        // optional (closed loop): near[3p] = the start index of this agent's nearest-index scan, near[3p+1] / [3p+2] = the largest / smallest of its three nearest indices (absolute), -1 = none
 };
 
 __device__ __forceinline__ double dist2d(double ax, double ay, double bx, double by) {
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     bool advance = true;
     const int pcut = a.prev_cut ? a.prev_cut[p] : 0;
     if (a.prev_save && lane == 0) a.prev_save[p] = pcut;
+    if (a.near && lane == 0) { a.near[3 * p] = tidx; a.near[3 * p + 1] = -1; a.near[3 * p + 2] = -1; }       // until the scan below has an answer
     // lane 0, next to every store of cut_len: the agent's place in the QP work queue of this step
     auto file_key = [&](int cl) {
         if (a.bin_cnt) {
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
             if (abs(bi[1] - bi[2]) == 2) tidx = bi[0] + t_old;
             else if (abs(bi[0] - bi[1]) == 1) tidx = max(bi[0], bi[1]) + t_old;
             else tidx = -1;
+            if (a.near && lane == 0 && tidx >= 0) { a.near[3 * p + 1] = t_old + max(bi[0], max(bi[1], bi[2])); a.near[3 * p + 2] = t_old + min(bi[0], min(bi[1], bi[2])); }
         }
     }
     if (tidx < 0) {
@@ -826,7 +829,8 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
     const size_t lds = (size_t)max_rem * sizeof(double) + ((size_t)fcap * sizeof(unsigned short) + 7) / 8 * 8;
     mpcx::InterArgs ia{*ip, P, state, path_xyyaw, path_cs, path_off, path_len, prev_cut_len, ctx->pred,
                        obs_off, obs_cnt, obs_skip, traj_idx, hit_idx, hit_xy, cut_len, max_rem, fcap, ctx->inter_prev_save,
-                       ctx->bin_hint, ctx->bin_hint ? ctx->bins : nullptr, ctx->bin_hint ? ctx->bins + MPCX_ORDER_COPIES * MPCX_ORDER_BINS : nullptr};
+                       ctx->bin_hint, ctx->bin_hint ? ctx->bins : nullptr, ctx->bin_hint ? ctx->bins + MPCX_ORDER_COPIES * MPCX_ORDER_BINS : nullptr,
+                       ctx->inter_near};
     hipLaunchKernelGGL(mpcx::interaction_kernel, dim3(P), dim3(64), lds, ctx->stream, ia);
     return mpcx_check_launch(ctx, "interaction kernels");
 }

@@ -53,11 +53,13 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
     // selection then writes the queue order and the plant kernel resets bins and ticket, so the counting sort costs no launch of its own.
     const bool binned = P < (1 << 24);
     ctx->inter_prev_save = ctx->prev_cut;
+    ctx->inter_near = ctx->prev_cut + P;             // (its start index, largest of its three nearest indices) per agent, for the window selection
     ctx->bin_hint = binned ? c->iters : nullptr;
     rc = mpcx_interaction_batch(ctx, ip, P, c->state, c->path_xyyaw, c->path_cs, c->path_off, c->path_len,
                                 c->cut_len /* previous step's cut; read before it is rewritten */, pool_rows, c->obs6,
                                 c->obs_off, c->obs_cnt, c->obs_skip, c->traj_idx, c->hit_idx, c->hit_xy, c->cut_len);
     ctx->inter_prev_save = nullptr;
+    ctx->inter_near = nullptr;
     ctx->bin_hint = nullptr;
     ctx->pack_state = nullptr; ctx->pack_applied = nullptr;
     if (rc != MPCX_OK) return rc;
@@ -67,8 +69,10 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
     const int Wd = ctx->mpc.T + 1;
     for (int pass = 0; pass < ctx->lin_passes; pass++) {
         ctx->bin_scatter = binned && pass == 0;
+        ctx->window_near = ctx->prev_cut + P; ctx->window_tidx = c->traj_idx;
         rc = mpcx_mpc_prepare_batch_ov(ctx, P, c->state, c->u_sol, c->path_xyyaw, c->path_v, c->path_off, c->cut_len, c->dl,
                                        c->target_ind, pass ? c->x_sol + 2 * Wd : nullptr, 4 * (int64_t)Wd, c->xref, c->reaches_end, c->xbar);
+        ctx->window_near = ctx->window_tidx = nullptr;
         if (rc != MPCX_OK) return rc;
         // (further linearisation passes build their order in line, from the iteration counts of the pass before)
         const int32_t *hint_before = ctx->order_hint, *now_before = ctx->order_now, *prev_before = ctx->order_prev;
@@ -148,7 +152,7 @@ extern "C" int32_t mpcx_closed_loop_run(mpcx_ctx *ctx, const mpcx_interaction_pa
     if ((size_t)c->P > ctx->prev_cut_cap) {
         if (ctx->prev_cut) (void)hipFree(ctx->prev_cut);
         ctx->prev_cut = nullptr; ctx->prev_cut_cap = 0;
-        if (hipMalloc((void **)&ctx->prev_cut, (size_t)c->P * sizeof(int32_t)) != hipSuccess)
+        if (hipMalloc((void **)&ctx->prev_cut, 4 * (size_t)c->P * sizeof(int32_t)) != hipSuccess)      // P cut lengths + 3 P nearest-index hints
             return mpcx_fail(ctx, MPCX_E_LAUNCH, "closed_loop_run: cannot allocate %d cut lengths", c->P);
         ctx->prev_cut_cap = (size_t)c->P;
     }

@@ -24,11 +24,15 @@ struct RefArgs {
     long ov_stride;
     const int32_t *bin_cnt, *keyslot;   // closed loop: the conflict search filed agent b as (key, slot) = keyslot[b]; its place in the QP work queue
     int32_t *order;                     // (keys descending) = number of agents with a larger key + slot.  nullptr: no queue order is built
+    // closed loop: the conflict search ran the same nearest-index scan for this agent (same state, same path) from near[3b]; near[3b+1] /
+    // [3b+2] = the largest / smallest of its three nearest indices or -1, near_tidx[b] = its answer.  nullptr: always scan
+    const int32_t *near, *near_tidx;
 };
 
 __device__ __forceinline__ void ref_window_block(const RefArgs &a, int b) {
     const int lane = threadIdx.x & 63;
     const int T = a.p.T, W = T + 1;
+#ifndef MPCX_WINDOW_ABLATE_ORDER      /* dev aid (timing only): what the queue scatter costs */
     if (a.order) {
         // lane k holds bin k.  Agents with a larger key come first (suffix sums over the bins by shuffles), then the agents of the same key
         // that counted in a lower copy of the bins, then the slot the conflict search drew
@@ -48,12 +52,24 @@ __device__ __forceinline__ void ref_window_block(const RefArgs &a, int b) {
         const int first = __shfl(sfx - c + lower, ks >> 24);
         if (lane == 0) a.order[first + (ks & 0xFFFFFF)] = b;
     }
+#endif
     const double *path = a.path + 3 * (size_t)a.path_off[b];
     const double *pv = a.path_v ? a.path_v + (size_t)a.path_off[b] : nullptr;   // mpc_with_speed.py:103-104
     const int n = a.path_len[b];
     const double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2];
     int start = a.target_ind[b];
-    int s = (start < 0 || n <= 0) ? -1 : nearest_index_in_direction(path, n, start, x, y, lane);
+#ifdef MPCX_WINDOW_ABLATE_SCAN          /* dev aid (timing only): what the nearest-index scan costs */
+    int s = start;
+#else
+    // The three nearest points of path[start .. n) are those of the conflict search's scan over path[hs .. len) whenever this range lies
+    // inside that one (start >= hs) and holds all three (the three smallest of a set are the three smallest of every subset that contains
+    // them; ties go to the lower index in both; the answer is a function of their absolute indices): then the answer is the conflict
+    // search's and the scan is skipped.  Else (an earlier start, a cut in front of one of the three, an ego that did not advance): scan.
+    int s;
+    const int hs = a.near ? a.near[3 * b] : -1, hm = a.near ? a.near[3 * b + 1] : -1, hl = a.near ? a.near[3 * b + 2] : -1;
+    if (hm >= 0 && start >= hs && hl >= start && hm < n) s = a.near_tidx[b];
+    else s = (start < 0 || n <= 0) ? -1 : nearest_index_in_direction(path, n, start, x, y, lane);
+#endif
     if (lane == 0) a.target_ind[b] = s;
     double *xr = a.xref + (size_t)b * 4 * W;
     uint8_t *re = a.re + (size_t)b * W;
@@ -215,7 +231,8 @@ extern "C" int32_t mpcx_mpc_prepare_batch_ov(mpcx_ctx *ctx, int32_t B, const dou
     const bool scatter = ctx->bin_scatter;
     ctx->bin_scatter = false;
     mpcx::RefArgs ra{ctx->mpc, B, state, path_xyyaw, path_v, path_off, path_len, dl, target_ind, xref, reaches_end, ov, (long)ov_stride,
-                     scatter ? ctx->bins : nullptr, scatter ? ctx->bins + MPCX_ORDER_COPIES * MPCX_ORDER_BINS : nullptr, scatter ? ctx->order : nullptr};
+                     scatter ? ctx->bins : nullptr, scatter ? ctx->bins + MPCX_ORDER_COPIES * MPCX_ORDER_BINS : nullptr, scatter ? ctx->order : nullptr,
+                     ctx->window_near, ctx->window_near ? ctx->window_tidx : nullptr};
     // the rollout may already be in flight: mpcx_closed_loop_run forks it at the start of the step, beside the conflict search
     const bool forked = ctx->rollout_forked;
     ctx->rollout_forked = false;
