@@ -107,14 +107,13 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // pred: obstacle disc centres [pool][steps][2][2]; (rem, rcs, n): the detailed path and cos/sin of its yaw.
 // Returns the index of the earliest conflicting pose on the detailed path (and its x,y) or -1 (None).
 //
-// Work distribution (round 2).  The reference's row order is frame-major, so the answer lies in the FIRST run of ego frames
-// that has any hit: runs are visited in order and the search stops after the first run with a hit.  Per run, every lane
-// tests the obstacle disc positions it holds in registers (8 per lane = 512 per chunk, one global load each) against the
-// run's inflated box and the survivors are compacted into an LDS queue with ballots; the queue is then worked off 64 entries
-// at a time, one (position, run) pair per lane with a uniform trip count -- no lane idles behind its neighbour's nested loops
-// (round 1: one position per lane through all runs; 7/8 of the issue slots of that loop ran with a handful of live lanes).
+// Work distribution.  The reference's row order is frame-major, so the answer lies in the FIRST run of ego frames that has any hit:
+// runs are visited in order and the search stops after the first run with a hit.  Per run, every lane tests the obstacle disc
+// positions it holds in registers (8 per lane = 512 per chunk, one global load each) against the run's inflated box into a bit mask and
+// works its own set bits off, all lanes on the same ego frame, leaving at the first frame with a hit anywhere in the wavefront
+// (round 1: one position per lane through all runs with nested divergent loops; rounds 2-3: survivors compacted into an LDS queue).
 constexpr int NSEG = 8;
-constexpr int QCAP = 8 * WAVE;      // a run's queue holds at most the candidates of one chunk (8 per lane)
+constexpr int QCAP = 8 * WAVE;      // (sizes the slack behind s_ego that used to hold the rounds 2-3 candidate queue; s_box lives there now)
 __device__ __forceinline__ double grp8_min(double v) {
     v = fmin(v, dpp_mov<0xB1>(v, v)); v = fmin(v, dpp_mov<0x4E>(v, v)); v = fmin(v, dpp_mov<0x141>(v, v));
     return v;
@@ -311,7 +310,7 @@ constexpr int MAXF_STATIC = MPCX_EGO_FRAMES_MAX;      // moving_collision_kernel
 __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     // dynamic LDS, sized by the host from the longest path of the call (mpcx_interaction_params.max_path_len):
     //   s_cum [max_rem] doubles   step / cumulative lengths of the remaining path; once the resampling has consumed them the
-    //                             same bytes hold s_ego [fcap][4] (ego disc centres per kept pose) and the candidate queue
+    //                             same bytes hold s_ego [fcap][4] (ego disc centres per kept pose) and s_box (the runs' boxes)
     //   s_keep [fcap] shorts      indices of the kept poses
     // (round 4: no static LDS, 16-bit indices, no candidate queue: 6464 B at the benchmark's capacity.  Six wavefronts per SIMD -- launch bound 6: 80 VGPRs, 64 B/lane of
     // scratch -- measured 0.138 ms against 0.122 at five: the kernel is bound by instruction issue, more wavefronts only share it)
@@ -817,7 +816,7 @@ extern "C" int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_
         hipLaunchKernelGGL(mpcx::predict_kernel, dim3((n_obs_pool + 63) / 64), dim3(64), 0, ctx->stream, pa);
     }
     // capacity: max_path_len path points (0 = MPCX_MAX_REMAINING; never below 512), rounded up to whole wavefronts; the LDS that
-    // holds their cumulative lengths later holds the ego discs of max_rem / 4 - 32 resampled poses and the 1 KB candidate queue.
+    // holds their cumulative lengths later holds the ego discs of max_rem / 4 - 32 resampled poses and the runs' boxes.
     // The kernel hides its memory latency with resident wavefronts (17 -> 11 blocks per CU costs 36 %), so the LDS follows the
     // call's longest path instead of a fixed 1024 points.
     int max_rem = ip->max_path_len > 0 ? ip->max_path_len : MPCX_MAX_REMAINING;
