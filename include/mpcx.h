@@ -202,6 +202,12 @@ typedef struct {
      * identical outputs either way. */
     const double *path_cum;
     double path_cum_err;
+    /* optional (NULL = off): per point k of the path table, the index (relative to the first point of ITS path) of the first point j <= k of
+     * that path with sqrt(dx*dx + dy*dy) <= 0.001 from point k -- get_cutoff_curve_by_position_idx (collision_avoidance.py:107-119) asked
+     * for the position of path point k, which is the only way mpc_intersection.py:125-131 ever asks it (collision_xy IS a path point).  A
+     * property of the path alone (k itself unless the path has duplicate points), evaluated once on the host with the reference's own
+     * expression; with it mpcx_interaction_batch looks the cut index up instead of scanning the path up to the conflict. */
+    const int32_t *path_first_within;
 } mpcx_interaction_params;
 int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip, int32_t P,
                                const double *state /*P,4*/,

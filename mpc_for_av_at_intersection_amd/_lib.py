@@ -29,7 +29,7 @@ class InteractionParamsC(C.Structure):
     _fields_ = [('pred_steps', C.c_int32), ('frame_window', C.c_int32),
                 ('cutoff_margin', C.c_int32), ('max_path_len', C.c_int32), ('dt', C.c_double), ('L', C.c_double), ('radius', C.c_double),
                 ('circle_centers', C.c_double * 4), ('max_accel', C.c_double), ('max_speed', C.c_double),
-                ('path_cum', C.c_void_p), ('path_cum_err', C.c_double)]
+                ('path_cum', C.c_void_p), ('path_cum_err', C.c_double), ('path_first_within', C.c_void_p)]
 
 
 class ClosedLoopC(C.Structure):

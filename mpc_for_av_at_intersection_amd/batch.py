@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .runtime import path_tables, Context, InteractionParams, MpcParams, MpcxError
+from .runtime import path_first_within, path_tables, Context, InteractionParams, MpcParams, MpcxError
 
 
 class IntersectionBatch:
@@ -71,6 +71,9 @@ class IntersectionBatch:
         cum, cum_err = path_tables(table, offs)
         self.path_cum = ctx.f64(cum)
         ip.path_cum, ip.path_cum_err = self.path_cum, cum_err
+        # ... and so is the answer of get_cutoff_curve_by_position_idx for every path point (the conflict search only ever asks it for one)
+        self.path_first_within = ctx.i32(path_first_within(table, offs))
+        ip.path_first_within = self.path_first_within
         r = route_of_agent.reshape(-1)
         s = start_index.reshape(-1)
         self.path_off = ctx.i32(offs[r])

@@ -719,14 +719,18 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     }
     // ---- collision_avoidance.py:107-119 on trajectory_full, then mpc_intersection.py:130-134
     int cut = 0x7fffffff;
-    {
+    if (ip.path_first_within) {
+        // (hx, hy) IS path point tidx + first: the first point within 1 mm of it is a property of the path, tabulated by the host with
+        // the reference's own expression (mpcx_interaction_params.path_first_within) -- no scan of the path up to the conflict
+        cut = ip.path_first_within[(size_t)a.path_off[p] + tidx + first];
+    } else {
         const double cr = 0.001, cr2lo = cr * cr * (1.0 - 1e-12), cr2hi = cr * cr * (1.0 + 1e-12);
         // (hx, hy) IS path point tidx + first, so the first index within 1 mm cannot lie beyond it: scan [0, tidx + first]
         const int jend = tidx + first + 1 < len ? tidx + first + 1 : len;
         for (int j = lane; j < jend; j += WAVE)         // same decision as sqrt(dx*dx + dy*dy) <= 0.001, no sqrt on the bulk
             if (within(path[3 * j], path[3 * j + 1], hx, hy, cr, cr2lo, cr2hi)) cut = j < cut ? j : cut;
+        cut = wave_min_i(cut);
     }
-    cut = wave_min_i(cut);
     int cl = len;
     if (cut != 0x7fffffff) { cl = cut - ip.cutoff_margin; cl = cl > tidx + 1 ? cl : tidx + 1; }
     if (lane == 0) { a.hit_idx[p] = first; a.hit_xy[2 * p] = hx; a.hit_xy[2 * p + 1] = hy; a.cut_len[p] = cl; file_key(cl); }

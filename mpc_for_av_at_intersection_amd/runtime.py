@@ -79,6 +79,7 @@ class InteractionParams:
     max_path_len: int = 0        # longest path of the batch in points (0 = the kernel's default capacity of 1024)
     path_cum: Optional[torch.Tensor] = None    # per point of the path table: arc length from the start of its path (device, float64) ...
     path_cum_err: float = 0.0                  # ... and the bound on the error of its differences (see mpcx_interaction_params; `path_tables()`)
+    path_first_within: Optional[torch.Tensor] = None   # per point: first point of its path within 1 mm of it (device, int32; `path_first_within()`)
 
     def to_c(self) -> _lib.InteractionParamsC:
         p = _lib.InteractionParamsC()
@@ -96,6 +97,7 @@ class InteractionParams:
         p.max_accel, p.max_speed = float(self.max_accel), float(self.max_speed)
         p.path_cum = None if self.path_cum is None else C.c_void_p(self.path_cum.data_ptr())
         p.path_cum_err = float(self.path_cum_err) if self.path_cum is not None else 0.0
+        p.path_first_within = None if self.path_first_within is None else C.c_void_p(self.path_first_within.data_ptr())
         return p
 
 
@@ -121,6 +123,23 @@ def path_tables(table: np.ndarray, offs) -> Tuple[np.ndarray, float]:
         n, length = b - a, float(cum[b - 1]) if b - a > 1 else 0.0
         worst = max(worst, 2.0 * (3 * n + 2) * 2.0 ** -53 * length)
     return cum, worst
+
+
+def path_first_within(table: np.ndarray, offs, radius: float = 0.001) -> np.ndarray:
+    """mpcx_interaction_params.path_first_within: for every point k of the concatenated path table (paths start at offs[0], offs[1], ...,
+    offs[-1] = n) the index, relative to its path's first point, of the first point j <= k of the same path with
+    np.linalg.norm(p_j - p_k) <= radius -- what get_cutoff_curve_by_position_idx(path, *p_k[:2]) returns (collision_avoidance.py:107-119),
+    with the reference's own numpy expression."""
+    table = np.asarray(table, dtype=np.float64)
+    out = np.zeros(len(table), dtype=np.int32)
+    for a, b in zip(offs[:-1], offs[1:]):
+        pts = table[a:b, :2]
+        for k0 in range(0, b - a, 256):                     # (k, j) blocks of 256 x n: bounded memory for long paths
+            k1 = min(k0 + 256, b - a)
+            diff = pts[None, :, :] - pts[k0:k1, None, :]      # points_diff[:, 0] -= x; points_diff[:, 1] -= y
+            near = np.linalg.norm(diff, axis=2) <= radius
+            out[a + k0:a + k1] = np.argmax(near, axis=1)     # first True; the point itself is always one
+    return out
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -357,6 +376,8 @@ class Context:
             self._want(t, i32, (Pn,), nm)
         if ip.path_cum is not None:
             self._want(ip.path_cum, torch.float64, (path.shape[0],), 'path_cum')
+        if ip.path_first_within is not None:
+            self._want(ip.path_first_within, torch.int32, (path.shape[0],), 'path_first_within')
         nobs = 0 if obs6 is None else obs6.shape[0]
         if out is None:
             out = dict(hit_idx=torch.empty(Pn, dtype=i32, device=self.device),

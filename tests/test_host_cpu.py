@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from mpc_for_av_at_intersection_amd import _lib
     assert ctypes.sizeof(_lib.MpcParamsC) == 8 + 8 * 23 + 8 + 8  # 2 int32 + 23 doubles + (model, reserved) + jerk_weight, no padding surprises
-    assert ctypes.sizeof(_lib.InteractionParamsC) == 16 + 8 * 9 + 8 + 8      # + path_cum pointer and its error bound (round 3)
+    assert ctypes.sizeof(_lib.InteractionParamsC) == 16 + 8 * 9 + 8 + 8 + 8  # + path_cum pointer and its error bound (round 3), path_first_within (round 4)
     assert ctypes.sizeof(_lib.AstarSearchC) == 8 * 20 + 8 + 16 == _lib.ASTAR_SEARCH_DTYPE.itemsize    # 20 doubles, hp_norm, 4 int32 (round 4)
     assert [_lib.ASTAR_SEARCH_DTYPE.fields[n][1] for n, _ in _lib.AstarSearchC._fields_] == [getattr(_lib.AstarSearchC, n).offset for n, _ in _lib.AstarSearchC._fields_]
     from oracle import oracle_py as orc
@@ -325,3 +325,31 @@ def test_vectorised_reference_expressions_equal_the_scalar_call_surface():
         assert np.array_equal(s._reference_edge(nodes, children, kk), np.array(scalar))
         seen.add((variant, bool(kw)))
     assert seen == {('multi_lane', False), ('multi_lane', True), ('roundabout', False), ('single_lane', False)}
+
+
+def test_path_first_within_is_the_cutoff_function_of_the_reference():
+    """runtime.path_first_within tabulates get_cutoff_curve_by_position_idx(path, *path[k, :2]) (collision_avoidance.py:107-119) for every
+    point k of every path: checked here against that function written out point by point, on paths with duplicate and near-duplicate
+    points (where the answer is not k itself)."""
+    import numpy as np
+    from mpc_for_av_at_intersection_amd.runtime import path_first_within
+    rng = np.random.default_rng(3)
+    paths = []
+    for n in (5, 40, 300, 700):
+        p = np.cumsum(rng.normal(0.0, 0.05, (n, 2)), axis=0)
+        dup = rng.choice(np.arange(1, n), max(1, n // 8), replace=False)
+        p[dup] = p[dup - 1] + rng.choice([0.0, 4e-4, 9.9e-4, 1.1e-3], (len(dup), 1)) * np.array([[0.6, 0.8]])   # copies, near copies, just outside
+        paths.append(np.column_stack([p, np.zeros(n)]))
+    table = np.concatenate(paths)
+    offs = np.cumsum([0] + [len(p) for p in paths])
+    got = path_first_within(table, offs)
+    differs = 0
+    for a, b in zip(offs[:-1], offs[1:]):
+        pts = table[a:b]
+        for k in range(b - a):
+            d = pts[:, :2].copy()
+            d[:, 0] -= pts[k, 0]; d[:, 1] -= pts[k, 1]
+            want = int(np.argmax(np.linalg.norm(d, axis=1) <= 0.001))
+            assert got[a + k] == want, (a, k, got[a + k], want)
+            differs += want != k
+    assert differs > 20
