@@ -208,6 +208,19 @@ typedef struct {
      * property of the path alone (k itself unless the path has duplicate points), evaluated once on the host with the reference's own
      * expression; with it mpcx_interaction_batch looks the cut index up instead of scanning the path up to the conflict. */
     const int32_t *path_first_within;
+    /* optional (plan_cnt = NULL: off; needs path_cum): the EGO PREDICTION of mpc_intersection.py:107-116 per path point.  Once the predicted
+     * speed v + MAX_ACCEL (i + 1) has reached MAX_SPEED -- after four points from standstill with the stock constants -- resample_curve's dl
+     * is the constant DT * MAX_SPEED, and as long as the few points before that stay in bucket 0 (checked per agent and step) the poses it
+     * keeps from trajectory_full[t:] depend on t alone: row t of the tables holds their number (plan_cnt[t]; 0 = not tabulated), the disc
+     * centres of the kept poses (plan_disc[t][plan_cap][4]: trajectories.py:11-37) and the boxes of the eight runs of frames the conflict
+     * search culls with (plan_box[t][8][4] = xlo, xhi, ylo, yhi, inflated), all computed on the host with the reference's own numpy
+     * expressions for plan_dl = DT * MAX_SPEED, plan_steps = pred_steps and the car's discs / radius.  path_disc[npts][4]: the disc centres
+     * of every path point (the earliest-pose scan of collision_avoidance.py:88-104 reads them instead of rebuilding them).  An agent
+     * whose step does not meet the condition takes the resampling pass as before: identical outputs either way. */
+    const int32_t *plan_cnt;
+    const double *plan_disc, *plan_box, *path_disc;
+    int32_t plan_cap, plan_steps;
+    double plan_dl, plan_radius;
 } mpcx_interaction_params;
 int32_t mpcx_interaction_batch(mpcx_ctx *ctx, const mpcx_interaction_params *ip, int32_t P,
                                const double *state /*P,4*/,

@@ -29,7 +29,9 @@ class InteractionParamsC(C.Structure):
     _fields_ = [('pred_steps', C.c_int32), ('frame_window', C.c_int32),
                 ('cutoff_margin', C.c_int32), ('max_path_len', C.c_int32), ('dt', C.c_double), ('L', C.c_double), ('radius', C.c_double),
                 ('circle_centers', C.c_double * 4), ('max_accel', C.c_double), ('max_speed', C.c_double),
-                ('path_cum', C.c_void_p), ('path_cum_err', C.c_double), ('path_first_within', C.c_void_p)]
+                ('path_cum', C.c_void_p), ('path_cum_err', C.c_double), ('path_first_within', C.c_void_p),
+                ('plan_cnt', C.c_void_p), ('plan_disc', C.c_void_p), ('plan_box', C.c_void_p), ('path_disc', C.c_void_p),
+                ('plan_cap', C.c_int32), ('plan_steps', C.c_int32), ('plan_dl', C.c_double), ('plan_radius', C.c_double)]
 
 
 class ClosedLoopC(C.Structure):

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .runtime import path_first_within, path_tables, Context, InteractionParams, MpcParams, MpcxError
+from .runtime import path_first_within, path_plan, path_tables, Context, InteractionParams, MpcParams, MpcxError
 
 
 class IntersectionBatch:
@@ -74,6 +74,17 @@ class IntersectionBatch:
         # ... and so is the answer of get_cutoff_curve_by_position_idx for every path point (the conflict search only ever asks it for one)
         self.path_first_within = ctx.i32(path_first_within(table, offs))
         ip.path_first_within = self.path_first_within
+        # ... and so is the ego prediction from every path point once the predicted speed has saturated (kept poses, their discs, run boxes)
+        pkey = (hash(table.tobytes()), tuple(int(o) for o in offs), float(ip.dt), float(ip.max_speed), tuple(float(v) for v in np.asarray(ip.circle_centers).ravel()),
+                float(ip.radius), int(ip.pred_steps))
+        pl = _PLAN_CACHE.get(pkey)
+        if pl is None:                   # (a few tenths of a second per set of routes: numpy over every start point of every route)
+            if len(_PLAN_CACHE) > 8:
+                _PLAN_CACHE.clear()
+            pl = _PLAN_CACHE[pkey] = path_plan(table, np.column_stack([np.cos(table[:, 2]), np.sin(table[:, 2])]), offs, ip.dt, ip.max_speed,
+                                               ip.circle_centers, ip.radius, ip.pred_steps)
+        self.plan = dict(pl, cnt=ctx.i32(pl['cnt']), disc=ctx.f64(pl['disc']), box=ctx.f64(pl['box']), path_disc=ctx.f64(pl['path_disc']))
+        ip.plan = self.plan
         r = route_of_agent.reshape(-1)
         s = start_index.reshape(-1)
         self.path_off = ctx.i32(offs[r])
@@ -265,6 +276,7 @@ def synthetic_batch(ctx: Context, B: int, A: int = 8, T: int = 20, seed: int = 0
     return IntersectionBatch(ctx, params, ip, routes, dl, route_of_agent, start, agent_shard=agent_shard, exchange=exchange)
 
 
+_PLAN_CACHE = {}
 ALL_STOCK_PAIRS = tuple((sp, ti) for sp in (1, 2, 3, 4) for ti in (1, 2, 3))
 
 

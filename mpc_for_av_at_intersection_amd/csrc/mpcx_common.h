@@ -15,7 +15,7 @@ struct mpcx_ctx {
     double *pred;        // scratch: predicted obstacle disc centres [NOBS][steps][2 discs][2]
     size_t pred_cap;     // capacity of pred in doubles
     hipGraphExec_t loop_exec;   // cached one-step graph of mpcx_closed_loop_run (nullptr = none)
-    unsigned char loop_key[640]; // descriptor + parameters the cached graph was captured for
+    unsigned char loop_key[768]; // descriptor + parameters the cached graph was captured for
     const mpcx_qp_tuning *tune; // per-instance tuning rows (device) or nullptr
     int32_t tune_rows;
     const int32_t *order_hint;  // iteration counts of a previous solve (device) or nullptr (mpcx_qp_set_order_hint)

@@ -135,7 +135,9 @@ __device__ __forceinline__ void divmod_small(int j, int d, float inv_d, int &quo
 
 __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)[4], int na, const double *pred,
                               int ooff, int nobs, int oskip, const double *rem, const double *rcs, int n,
-                              double (*s_box)[4], int lane, double &hx, double &hy
+                              double (*s_box)[4], int lane, double &hx, double &hy,
+                              bool boxes_ready = false,          // s_box already holds the runs' boxes (mpcx_interaction_params.plan_box)
+                              const double *pdisc = nullptr      // disc centres of the poses of `rem` (mpcx_interaction_params.path_disc + 4 * row of rem[0]) or nullptr
 #ifdef MPCX_INTER_PROFILE
                               , unsigned long long *fc_prof = nullptr
 #endif
@@ -157,7 +159,7 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
     // Lane (run = lane / 8, j = lane % 8) folds frames run*SL + j, + 8, ...; an 8-lane butterfly finishes the run.
     const int F = na > steps ? na : steps;
     const int SL = (F + NSEG - 1) / NSEG;                 // frames per run
-    {
+    if (!boxes_ready) {
         const int sg = lane >> 3, j = lane & 7;
         const int fend = (sg + 1) * SL < F ? (sg + 1) * SL : F;
         double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
@@ -281,13 +283,15 @@ __device__ int first_conflict(const mpcx_interaction_params &ip, double (*s_ego)
             for (int k = 0; k < PD; k++) {
                 const int i = i0 + k * WAVE + lane;
                 const int ic = i < n ? i : n - 1;             // clamped address, masked below
-                px[k] = rem[3 * ic]; py[k] = rem[3 * ic + 1]; pc[k] = rcs[2 * ic]; ps[k] = rcs[2 * ic + 1];
+                if (pdisc) { px[k] = pdisc[4 * (size_t)ic + 2 * d]; py[k] = pdisc[4 * (size_t)ic + 2 * d + 1]; pc[k] = 0.0; ps[k] = 0.0; }
+                else { px[k] = rem[3 * ic]; py[k] = rem[3 * ic + 1]; pc[k] = rcs[2 * ic]; ps[k] = rcs[2 * ic + 1]; }
             }
 #pragma unroll
             for (int k = 0; k < PD; k++) {
                 const int i = i0 + k * WAVE + lane;
-                const double ex = __dadd_rn(__dadd_rn(__dmul_rn(pc[k], cx), -__dmul_rn(ps[k], cy)), px[k]);
-                const double ey = __dadd_rn(__dadd_rn(__dmul_rn(ps[k], cx), __dmul_rn(pc[k], cy)), py[k]);
+                // (with the host's table the disc centre is read, not rebuilt: px, py hold it)
+                const double ex = pdisc ? px[k] : __dadd_rn(__dadd_rn(__dmul_rn(pc[k], cx), -__dmul_rn(ps[k], cy)), px[k]);
+                const double ey = pdisc ? py[k] : __dadd_rn(__dadd_rn(__dmul_rn(ps[k], cx), __dmul_rn(pc[k], cy)), py[k]);
                 const bool hit = i < n && within(ox, oy, ex, ey, md, md2lo, md2hi);
                 const unsigned long long m = __ballot(hit);
                 if (m && first == 0x7fffffff) first = d * n + i0 + k * WAVE + (int)__ffsll((long long)m) - 1;      // wave-uniform
@@ -307,7 +311,7 @@ constexpr int MAXF_STATIC = MPCX_EGO_FRAMES_MAX;      // moving_collision_kernel
 #else
 #define ISTAMP(k) do {} while (0)
 #endif
-__global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
+__global__ __launch_bounds__(64, 5) void interaction_kernel(InterArgs a) {
     // dynamic LDS, sized by the host from the longest path of the call (mpcx_interaction_params.max_path_len):
     //   s_cum [max_rem] doubles   step / cumulative lengths of the remaining path; once the resampling has consumed them the
     //                             same bytes hold s_ego [fcap][4] (ego disc centres per kept pose) and s_box (the runs' boxes)
@@ -654,9 +658,48 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
         }
         return base;
     };
-    bool unsure;
-    int na;
-    if (search_ok) {
+    bool unsure = false;
+    int na = 0;
+    // Round 4: the ego prediction from the host's table (mpcx_interaction_params.plan_*).  Once the predicted speed has saturated dl is the
+    // constant DT * MAX_SPEED; if the points before that (four from standstill with the stock constants) all stay in bucket 0 with their
+    // own, smaller dl -- then they do with the constant one too -- the bucket sequence of trajectory_full[tidx:] is the one the host
+    // resampled with the constant dl, i.e. the kept poses depend on tidx alone: their number, their disc centres and the run boxes are ONE
+    // read of row tidx (one memory round trip) instead of the resampling pass, the disc arithmetic and the box reductions.
+    bool plan_ok = false;
+    const size_t prow = (size_t)a.path_off[p] + tidx;
+#ifndef MPCX_INTER_FORCE_EXACT
+    if (ip.plan_cnt && tab && ip.plan_dl == dl_const && ip.plan_steps == ip.pred_steps && ip.plan_radius == ip.radius && ip.plan_cap <= MAXF && ip.plan_cap <= WAVE) {
+        const int cnt = ip.plan_cnt[prow];
+        // the row's disc centres and boxes are requested together with its count (the table has plan_cap poses per row whatever the count is):
+        // one memory round trip, not two
+        const double *pd = ip.plan_disc + prow * (size_t)ip.plan_cap * 4;
+        const int f0 = lane < 2 * ip.plan_cap ? lane : 0, f1 = lane + WAVE < 2 * ip.plan_cap ? lane + WAVE : 0;
+        const double e0x = pd[2 * f0], e0y = pd[2 * f0 + 1], e1x = pd[2 * f1], e1y = pd[2 * f1 + 1];
+        const double bxv = ip.plan_box[prow * (4 * NSEG) + (lane < 4 * NSEG ? lane : 0)];
+        // lane i: has the predicted speed of point i reached MAX_SPEED?  (monotone in i for max_accel >= 0)
+        const bool sat = !accel_phase || !(__dadd_rn(__dmul_rn(ip.max_accel, (double)(lane + 1)), v) < ip.max_speed);
+        const unsigned long long sm = __ballot(sat);
+        const int isat = sm ? (int)__ffsll((long long)sm) - 1 : WAVE;
+        bool bad = false;
+        if (lane < isat && lane < n) {       // points with their own dl: bucket 0 needs c_i < dl_i, with the table's error bound on the safe side
+            const double r = __dadd_rn(__dmul_rn(ip.max_accel, (double)(lane + 1)), v);
+            const double dli = __dmul_rn(ip.dt, r);
+            const double ci = cumtab[tidx + lane] - cum0;
+            bad = !(ci + marg < dli * (1.0 - 1e-12)) || !(dli > 0.0);
+        }
+        plan_ok = cnt > 0 && cnt <= ip.plan_cap && ip.max_accel >= 0.0 && isat < WAVE && !__ballot(bad);
+        if (plan_ok) {
+            na = cnt;
+            // lane f handles disc f & 1 of pose f >> 1 (and f + 64 likewise; plan_cap <= 64 poses)
+            if (lane < 2 * na) { s_ego[lane >> 1][2 * (lane & 1)] = e0x; s_ego[lane >> 1][2 * (lane & 1) + 1] = e0y; }
+            if (lane + WAVE < 2 * na) { s_ego[(lane + WAVE) >> 1][2 * (lane & 1)] = e1x; s_ego[(lane + WAVE) >> 1][2 * (lane & 1) + 1] = e1y; }
+            if (lane < 4 * NSEG) (&s_box[0][0])[lane] = bxv;
+        }
+    }
+#endif
+    if (plan_ok) {
+        ISTAMP(2);
+    } else if (search_ok) {
         ISTAMP(2);
         na = resample_search(unsure);
     } else {
@@ -688,6 +731,7 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     __syncthreads();
     ISTAMP(3);      // resample
     // ego disc centres per kept pose
+    if (!plan_ok)
     for (int f = lane; f < na; f += WAVE) {
         const int i = s_keep[f];
         const double px = rem[3 * i], py = rem[3 * i + 1], c = rcs[2 * i], s = rcs[2 * i + 1];
@@ -703,10 +747,12 @@ __global__ __launch_bounds__(64, 4) void interaction_kernel(InterArgs a) {
     const int ooff = a.obs_off[p], oskip = a.obs_skip ? a.obs_skip[p] : -1;
     double hx, hy;
 #ifdef MPCX_INTER_PROFILE
-    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, lane, hx, hy,
+    const double *pdisc = ip.plan_cnt ? ip.path_disc + 4 * prow : nullptr;     // disc centres of trajectory_full[tidx:] from the host's table
+    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, lane, hx, hy, plan_ok, pdisc,
                                      (unsigned long long *)(a.hit_xy + 2 * (size_t)a.P) + 16 * (size_t)p);
 #else
-    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, lane, hx, hy);
+    const double *pdisc = ip.plan_cnt ? ip.path_disc + 4 * prow : nullptr;     // disc centres of trajectory_full[tidx:] from the host's table
+    const int first = first_conflict(ip, s_ego, na, a.pred, ooff, nobs, oskip, rem, rcs, n, s_box, lane, hx, hy, plan_ok, pdisc);
 #endif
     ISTAMP(5);      // conflict search (+ path scan on a hit)
     if (first < 0) {

@@ -80,6 +80,7 @@ class InteractionParams:
     path_cum: Optional[torch.Tensor] = None    # per point of the path table: arc length from the start of its path (device, float64) ...
     path_cum_err: float = 0.0                  # ... and the bound on the error of its differences (see mpcx_interaction_params; `path_tables()`)
     path_first_within: Optional[torch.Tensor] = None   # per point: first point of its path within 1 mm of it (device, int32; `path_first_within()`)
+    plan: Optional[dict] = None                # ego prediction per path point (`path_plan()` uploaded: cnt, disc, box, path_disc tensors + cap, steps, dl, radius)
 
     def to_c(self) -> _lib.InteractionParamsC:
         p = _lib.InteractionParamsC()
@@ -98,6 +99,10 @@ class InteractionParams:
         p.path_cum = None if self.path_cum is None else C.c_void_p(self.path_cum.data_ptr())
         p.path_cum_err = float(self.path_cum_err) if self.path_cum is not None else 0.0
         p.path_first_within = None if self.path_first_within is None else C.c_void_p(self.path_first_within.data_ptr())
+        if self.plan is not None and self.path_cum is not None:
+            pl = self.plan
+            p.plan_cnt, p.plan_disc, p.plan_box, p.path_disc = (C.c_void_p(pl[k].data_ptr()) for k in ('cnt', 'disc', 'box', 'path_disc'))
+            p.plan_cap, p.plan_steps, p.plan_dl, p.plan_radius = int(pl['cap']), int(pl['steps']), float(pl['dl']), float(pl['radius'])
         return p
 
 
@@ -140,6 +145,60 @@ def path_first_within(table: np.ndarray, offs, radius: float = 0.001) -> np.ndar
             near = np.linalg.norm(diff, axis=2) <= radius
             out[a + k0:a + k1] = np.argmax(near, axis=1)     # first True; the point itself is always one
     return out
+
+
+def path_plan(table: np.ndarray, cs: np.ndarray, offs, dt: float, max_speed: float, circle_centers, radius: float, pred_steps: int,
+              cap: int = 64, n_runs: int = 8) -> dict:
+    """mpcx_interaction_params.plan_*: for every point t of the concatenated path table the ego prediction the scenario loop builds from
+    trajectory_full[t:] once the predicted speed has saturated (mpc_intersection.py:107-116: resample_curve with dl = DT * MAX_SPEED),
+    evaluated with the reference's own numpy expressions: which poses are kept (trajectories.py:58-86, np.cumsum restarted at t), their
+    disc centres (trajectories.py:11-37 with the host's cos / sin of the yaw column) and, for the conflict search's cull, the bounding
+    boxes of `n_runs` runs of frames of the padded prediction (max(kept, pred_steps) frames), inflated by a little more than 2 * radius.
+    Returns numpy arrays cnt (npts,), disc (npts, cap, 4), box (npts, n_runs, 4), path_disc (npts, 4) + cap, steps, dl, radius."""
+    table = np.asarray(table, dtype=np.float64)
+    cs = np.asarray(cs, dtype=np.float64)
+    npts = len(table)
+    cc = np.asarray(circle_centers, dtype=np.float64).reshape(-1, 2)
+    if len(cc) == 1:
+        cc = np.repeat(cc, 2, axis=0)
+    c, s = cs[:, 0], cs[:, 1]
+    path_disc = np.empty((npts, 4))
+    for d in range(2):
+        path_disc[:, 2 * d] = (c * cc[d, 0] - s * cc[d, 1]) + table[:, 0]
+        path_disc[:, 2 * d + 1] = (s * cc[d, 0] + c * cc[d, 1]) + table[:, 1]
+    dl = dt * max_speed
+    md = 2.0 * radius
+    slack = md * (1.0 + 1e-9) + 1e-9
+    cnt = np.zeros(npts, dtype=np.int32)
+    disc = np.zeros((npts, cap, 4))
+    box = np.empty((npts, n_runs, 4))
+    box[:, :, 0::2] = np.inf; box[:, :, 1::2] = -np.inf
+    for a, b in zip(offs[:-1], offs[1:]):
+        if b - a < 1:
+            continue
+        seg = np.append(0.0, np.linalg.norm(table[a + 1:b, :2] - table[a:b - 1, :2], axis=1))      # seg[i]: step into point i of the path
+        for t in range(a, b):
+            steps = seg[t - a:].copy()
+            steps[0] = 0.0                                  # np.append(0., norm(diff)) of the sub-path starting at t
+            bucket = np.floor(steps.cumsum() / dl).astype(int)
+            keep = np.append(True, (bucket[1:] - bucket[:-1]) >= 1.)
+            keep[-1] = True
+            idx = np.nonzero(keep)[0]
+            k = len(idx)
+            if k > cap:
+                continue                                    # not tabulated: the kernel resamples
+            cnt[t] = k
+            ego = path_disc[t + idx]
+            disc[t, :k] = ego
+            F = max(k, pred_steps)
+            SL = (F + n_runs - 1) // n_runs
+            padded = ego[np.minimum(np.arange(F), k - 1)]   # frames beyond the prediction repeat its last pose
+            for sg in range(n_runs):
+                run = padded[sg * SL:(sg + 1) * SL]
+                if len(run):
+                    xs, ys = run[:, 0::2], run[:, 1::2]
+                    box[t, sg] = (xs.min() - slack, xs.max() + slack, ys.min() - slack, ys.max() + slack)
+    return dict(cnt=cnt, disc=disc, box=box, path_disc=path_disc, cap=cap, steps=int(pred_steps), dl=dl, radius=float(radius))
 
 
 def _ptr(t: Optional[torch.Tensor]):

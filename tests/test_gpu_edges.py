@@ -195,13 +195,14 @@ def test_arc_length_table_changes_nothing(ctx):
     from mpc_for_av_at_intersection_amd.batch import stock_routes, synthetic_batch
     routes, dl, cd = stock_routes(ctx)
     sim = synthetic_batch(ctx, B=96, A=8, T=20, seed=5, routes=routes, dl=dl, cd=cd)
-    assert sim.ip.path_cum is not None and 0 < sim.ip.path_cum_err < 1e-9
+    assert sim.ip.path_cum is not None and 0 < sim.ip.path_cum_err < 1e-9 and sim.ip.plan is not None
     for burn in (3, 40):
         sim.run(burn)
         ctx.synchronize()
         outs = []
-        for ip in (dataclasses.replace(sim.ip, path_cum=None, path_first_within=None), sim.ip, dataclasses.replace(sim.ip, path_cum_err=1.0),
-                   dataclasses.replace(sim.ip, path_first_within=None)):
+        for ip in (dataclasses.replace(sim.ip, path_cum=None, path_first_within=None, plan=None), sim.ip, dataclasses.replace(sim.ip, path_cum_err=1.0),
+                   dataclasses.replace(sim.ip, path_first_within=None), dataclasses.replace(sim.ip, plan=None),
+                   dataclasses.replace(sim.ip, plan=None, path_cum_err=1.0)):
             tr = sim.traj_idx.clone()
             o = ctx.interaction(ip, sim.state, sim.path, sim.path_cs, sim.path_off, sim.path_len, sim.inter['cut_len'].clone(), sim.obs6,
                                 sim.obs_off, sim.obs_cnt, sim.obs_skip, tr)
@@ -236,8 +237,9 @@ def test_resampling_by_search_on_unevenly_sampled_paths(ctx):
         sim.run(burn)
         ctx.synchronize()
         outs = []
-        for ip in (dataclasses.replace(sim.ip, path_cum=None, path_first_within=None), sim.ip, dataclasses.replace(sim.ip, path_cum_err=1.0),
-                   dataclasses.replace(sim.ip, path_first_within=None)):
+        for ip in (dataclasses.replace(sim.ip, path_cum=None, path_first_within=None, plan=None), sim.ip, dataclasses.replace(sim.ip, path_cum_err=1.0),
+                   dataclasses.replace(sim.ip, path_first_within=None), dataclasses.replace(sim.ip, plan=None),
+                   dataclasses.replace(sim.ip, plan=None, path_cum_err=1.0)):
             tr = sim.traj_idx.clone()
             o = ctx.interaction(ip, sim.state, sim.path, sim.path_cs, sim.path_off, sim.path_len, sim.inter['cut_len'].clone(), sim.obs6,
                                 sim.obs_off, sim.obs_cnt, sim.obs_skip, tr)

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from mpc_for_av_at_intersection_amd import _lib
     assert ctypes.sizeof(_lib.MpcParamsC) == 8 + 8 * 23 + 8 + 8  # 2 int32 + 23 doubles + (model, reserved) + jerk_weight, no padding surprises
-    assert ctypes.sizeof(_lib.InteractionParamsC) == 16 + 8 * 9 + 8 + 8 + 8  # + path_cum pointer and its error bound (round 3), path_first_within (round 4)
+    assert ctypes.sizeof(_lib.InteractionParamsC) == 16 + 8 * 9 + 8 + 8 + 8 + 4 * 8 + 8 + 16  # + path_cum pointer and its error bound (round 3), path_first_within, plan_* (round 4)
     assert ctypes.sizeof(_lib.AstarSearchC) == 8 * 20 + 8 + 16 == _lib.ASTAR_SEARCH_DTYPE.itemsize    # 20 doubles, hp_norm, 4 int32 (round 4)
     assert [_lib.ASTAR_SEARCH_DTYPE.fields[n][1] for n, _ in _lib.AstarSearchC._fields_] == [getattr(_lib.AstarSearchC, n).offset for n, _ in _lib.AstarSearchC._fields_]
     from oracle import oracle_py as orc
@@ -353,3 +353,40 @@ def test_path_first_within_is_the_cutoff_function_of_the_reference():
             assert got[a + k] == want, (a, k, got[a + k], want)
             differs += want != k
     assert differs > 20
+
+
+def test_path_plan_is_the_scenario_loops_ego_prediction():
+    """runtime.path_plan tabulates, per path point t, the ego prediction of main/scenarios/mpc_intersection.py:107-116 for a saturated speed
+    (resample_curve(trajectory_full[t:], dl = DT * MAX_SPEED), trajectories.py:58-86), the disc centres of the kept poses
+    (trajectories.py:11-37) and conservative boxes of eight runs of frames: checked against lib.trajectories' own functions (the mirror
+    of the reference's that the golden vectors pin) on a stock route and on an unevenly sampled one."""
+    import numpy as np
+    from mpc_for_av_at_intersection_amd.lib.car_dimensions import BicycleModelDimensions
+    from mpc_for_av_at_intersection_amd.lib.trajectories import car_trajectory_to_collision_point_trajectories, resample_curve
+    from mpc_for_av_at_intersection_amd.runtime import path_plan
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'mpc_pre.npz'))
+    full = g['path_4_1']
+    rng = np.random.default_rng(5)
+    thin = full[np.sort(np.concatenate([[0, len(full) - 1], rng.choice(np.arange(1, len(full) - 1), len(full) // 3, replace=False)]))]
+    cd = BicycleModelDimensions()
+    table = np.concatenate([full, thin])
+    offs = np.array([0, len(full), len(full) + len(thin)])
+    dt, vmax, steps = 0.2, 30.0 / 3.6, 35
+    pl = path_plan(table, np.column_stack([np.cos(table[:, 2]), np.sin(table[:, 2])]), offs, dt, vmax, np.asarray(cd.circle_centers).ravel(), cd.radius, steps)
+    assert pl['disc'].shape == (len(table), 64, 4) and pl['box'].shape == (len(table), 8, 4)
+    for a, b in zip(offs[:-1], offs[1:]):
+        for t in list(range(a, b, 37)) + [b - 2, b - 1]:
+            res = resample_curve(table[t:b], dl=dt * vmax)
+            k = len(res)
+            assert pl['cnt'][t] == k
+            front, rear = car_trajectory_to_collision_point_trajectories(res, cd)
+            assert np.array_equal(pl['disc'][t, :k, 0:2], front[:, :2]) and np.array_equal(pl['disc'][t, :k, 2:4], rear[:, :2])
+            # every disc of every (padded) frame lies inside its run's box with room for 2 * radius
+            F = max(k, steps); SL = (F + 7) // 8
+            for f in range(F):
+                e = pl['disc'][t, min(f, k - 1)]
+                bx = pl['box'][t, f // SL]
+                assert bx[0] <= e[0::2].min() - 2 * cd.radius and bx[1] >= e[0::2].max() + 2 * cd.radius
+                assert bx[2] <= e[1::2].min() - 2 * cd.radius and bx[3] >= e[1::2].max() + 2 * cd.radius
+    full_disc = car_trajectory_to_collision_point_trajectories(table, cd)
+    assert np.array_equal(pl['path_disc'][:, 0:2], full_disc[0][:, :2]) and np.array_equal(pl['path_disc'][:, 2:4], full_disc[1][:, :2])
