@@ -13,6 +13,7 @@ Successors, collision flags and edge costs come from mpcx_expand_batch (one laun
 with the best open nodes and, in a second launch, all of their free children, so most pops hit the cache); the
 queue, heuristic and goal test stay on the host (exact float semantics of a_star.py).
 """
+import os
 from typing import Dict, Iterable, List, Tuple
 
 import numpy as np
@@ -144,7 +145,11 @@ class MotionPrimitiveSearch:
         obst = c.inv_obstacle_distance(children[:, 0], children[:, 1]) if self._wh_obstacle != 0.0 else 0.0     # (sic) gated on the HEURISTIC weight
         centre = 0.0
         if self._wc_center != 0.0:
-            centre = np.array([float(np.linalg.norm([px, py])) for px, py in children[:, :2].tolist()])
+            # np.linalg.norm([x, y]) goes through BLAS ddot (whose rounding -- fused or not -- is the library's business): evaluated with that
+            # very call, once per DISTINCT point (a batch of replicated or overlapping searches repeats its successors many times over)
+            keys = np.ascontiguousarray(children[:, :2]).view(np.complex128).ravel()       # (x, y) as one sortable scalar: a 1-D unique, not a row sort
+            uniq, inv = np.unique(keys, return_inverse=True)
+            centre = np.array([float(np.linalg.norm([px, py])) for px, py in zip(uniq.real.tolist(), uniq.imag.tolist())])[inv.ravel()]
         return self._wc_dist * length + self._wc_steering * steer + self._wc_obstacle * obst + self._wc_center * centre
 
     def distance_to_goal(self, node: NodeType) -> float:
@@ -376,10 +381,33 @@ class _DeviceCheck:
         return self._norm_dev
 
     def inv_obstacle_distance(self, x, y):
-        """1 / distance_to_nearest_obstacle (inf where the distance is 0) at points (x, y), element-wise IEEE arithmetic in the reference's order"""
+        """1 / distance_to_nearest_obstacle (inf where the distance is 0) at points (x, y), element-wise IEEE arithmetic in the reference's order:
+        abs((a * x + b * y) + c) / norm per half-plane row, minimum over the rows.  points x rows is tens of millions of elements for a batch
+        of searches: evaluated in cache-sized chunks of points, in place, on a few threads (numpy releases the GIL inside its loops)."""
         r = self.rows
-        d = np.abs(r[None, :, 0] * x[:, None] + r[None, :, 1] * y[:, None] + r[None, :, 2]) / self.norm[None, :]
-        d = d.min(axis=1) if r.shape[0] else np.full(len(x), np.inf)
+        n = len(x)
+        if r.shape[0] == 0:
+            return np.zeros(n)                               # min over nothing = inf, 1 / inf = 0
+        x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        a, b, c, nrm = r[None, :, 0], r[None, :, 1], r[None, :, 2], self.norm[None, :]
+        d = np.empty(n)
+
+        def work(lo):
+            hi = min(lo + 2048, n)
+            t = a * x[lo:hi, None]
+            t += b * y[lo:hi, None]
+            t += c
+            np.abs(t, out=t)
+            t /= nrm
+            d[lo:hi] = t.min(axis=1)
+        starts = range(0, n, 2048)
+        if n > 8192:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+                list(pool.map(work, starts))
+        else:
+            for lo in starts:
+                work(lo)
         with np.errstate(divide='ignore'):
             return np.where(d != 0.0, 1.0 / d, np.inf)
 
