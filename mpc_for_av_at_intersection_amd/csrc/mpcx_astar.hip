@@ -134,10 +134,10 @@ __device__ __forceinline__ double steering_change(double current_th, double next
 }
 // distance_to_nearest_obstacle (_multi_lane.py:78-108): min over every half-plane row of |a x + b y + c| / (a**2 + b**2)**0.5; the whole
 // wavefront calls it with the same point, lane l takes rows l, l + 64, ...
-__device__ __forceinline__ double nearest_obstacle(const double *hp, const double *norm, int n_rows, double x, double y, int lane) {
+__device__ __forceinline__ double nearest_obstacle(const double *rows4, int n_rows, double x, double y, int lane) {      // rows4: (a, b, c, norm) per row, in LDS
     double best = INFINITY;
     for (int r = lane; r < n_rows; r += WAVE) {
-        const double v = fabs(__dadd_rn(__dadd_rn(mul_rn(hp[3 * r], x), mul_rn(hp[3 * r + 1], y)), hp[3 * r + 2])) / norm[r];
+        const double v = fabs(__dadd_rn(__dadd_rn(mul_rn(rows4[4 * r], x), mul_rn(rows4[4 * r + 1], y)), rows4[4 * r + 2])) / rows4[4 * r + 3];
         best = v < best ? v : best;
     }
 #pragma unroll
@@ -199,6 +199,16 @@ __global__ __launch_bounds__(64) void astar_kernel(AstarIO io) {
     const ExpandArgs &a = sa.model;
     const mpcx_astar_search &sp = sa.sp;
     expand_stage(a, t);
+    // searches with an obstacle-distance term: ALL half-plane rows of the model with the host's row norms, staged once (dynamic LDS, sized by
+    // the launch for the largest model that needs it; nine successors per expansion read every row)
+    extern __shared__ double s_rows4[];
+    if (needs_obstacle_term(sp)) {
+        for (int r = lane; r < sa.n_rows_all; r += WAVE) {
+            s_rows4[4 * r] = sa.hp_all[3 * r]; s_rows4[4 * r + 1] = sa.hp_all[3 * r + 1]; s_rows4[4 * r + 2] = sa.hp_all[3 * r + 2];
+            s_rows4[4 * r + 3] = sp.hp_norm[r];
+        }
+        __syncthreads();
+    }
     double *heap = io.heap + (size_t)sidx * io.heap_cap * HE;
     double *tab = io.table + (size_t)sidx * io.table_cap * TE;
     double *log = io.log + (size_t)sidx * io.log_cap * 8;
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(64) void astar_kernel(AstarIO io) {
             if (!free_k) continue;
             double obst = 0.0;
             if (want_obst) {
-                const double dn = nearest_obstacle(sa.hp_all, sp.hp_norm, sa.n_rows_all, sx, sy, lane);
+                const double dn = nearest_obstacle(s_rows4, sa.n_rows_all, sx, sy, lane);
                 obst = dn != 0.0 ? 1.0 / dn : INFINITY;          // 1 / d if d else float('inf')
             }
             double edge = edge_value(sp, a.edge_cost[k], nth, sx, sy, sth, obst);
@@ -408,6 +418,7 @@ extern "C" int32_t mpcx_astar_batch(mpcx_ctx *ctx, int32_t n_search, const mpcx_
         !b->heap || !b->table || !b->log || !b->push_log || !b->path || !b->path_prim || !b->cost || !b->miss || !b->status || !b->n_exp || !b->n_push || !b->path_len)
         return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: buffers missing, capacities too small or table_cap not a power of two");
     std::vector<mpcx::AstarArgs> host((size_t)n_search);
+    int max_obst_rows = 0;
     for (int i = 0; i < n_search; i++) {
         const mpcx_search_model *m = models[i];
         const mpcx_astar_search &sp = searches[i];
@@ -424,7 +435,9 @@ extern "C" int32_t mpcx_astar_batch(mpcx_ctx *ctx, int32_t n_search, const mpcx_
         host[i].sp = sp;
         host[i].hp_all = m->d_hp;
         host[i].n_rows_all = m->n_rows;
+        if (mpcx::needs_obstacle_term(sp) && m->n_rows > max_obst_rows) max_obst_rows = m->n_rows;
     }
+    if (max_obst_rows > 1024) return mpcx_fail(ctx, MPCX_E_INVALID, "astar_batch: %d half-plane rows exceed the 1024 the obstacle-distance term stages in LDS", max_obst_rows);
     const size_t need = host.size() * sizeof(mpcx::AstarArgs);
     if (need > ctx->multi_cap) {
         if (ctx->multi) (void)hipFree(ctx->multi);
@@ -438,6 +451,6 @@ extern "C" int32_t mpcx_astar_batch(mpcx_ctx *ctx, int32_t n_search, const mpcx_
     mpcx::AstarIO io{n_search, (const mpcx::AstarArgs *)ctx->multi, n_cs, cs_theta, cs_val, n_ov, ov_key, ov_val,
                      b->heap_cap, b->table_cap, b->log_cap, b->push_cap, b->path_cap, b->heap, b->table, b->log, b->push_log, b->path, b->cost, b->miss,
                      b->status, b->n_exp, b->n_push, b->path_len, b->path_prim};
-    hipLaunchKernelGGL(mpcx::astar_kernel, dim3(n_search), dim3(64), 0, ctx->stream, io);
+    hipLaunchKernelGGL(mpcx::astar_kernel, dim3(n_search), dim3(64), (size_t)max_obst_rows * 4 * sizeof(double), ctx->stream, io);
     return mpcx_check_launch(ctx, "astar_kernel");
 }
