@@ -242,11 +242,13 @@ def main():
         iters_sum.zero_(); fail_sum.zero_()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            sim.step()
-            if staged:
+        if staged:
+            for _ in range(steps):
+                sim.step()
                 iters_sum.add_(sim.sol['iters'].sum())
                 fail_sum.add_((sim.sol['status'] != 0).sum())
+        else:
+            sim.run(steps)          # ONE mpcx_closed_loop_run call: `steps` steps enqueued back to back
         barrier()
         el = time.perf_counter() - t0
         qp_ms, qp_n = ctx.profile_qp_read()

@@ -186,6 +186,28 @@ def test_linearisation_passes_batch_equals_staged(ctx):
     assert (a['status'] == 0).all() and not np.array_equal(a['u'], c['u'])
 
 
+def test_one_call_of_n_steps_equals_n_calls_of_one_step(ctx):
+    """mpcx_closed_loop_run(n) enqueues n steps back to back (what bench.py times): every output -- states, applied inputs, solutions, cut
+    lengths, indices, run statistics -- must be bit-identical to stepping one call at a time, for the stage solver and for the condensed
+    one (with its second-chance launch), with two linearisation passes, and for calls of mixed lengths."""
+    from mpc_for_av_at_intersection_amd.batch import synthetic_batch
+    for B, kw in ((64, {}), (1536, {}), (48, dict(lin=2))):
+        sims = [synthetic_batch(ctx, B=B, A=8, T=20, seed=9) for _ in range(2)]
+        for s in sims:
+            s.lin_passes = kw.get('lin', 1)
+        ctx.closed_loop_stats(reset=True)
+        sims[0].run(3); sims[0].run(11); sims[0].run(1); sims[0].run(6)
+        st_a = ctx.closed_loop_stats(reset=True)
+        for _ in range(21):
+            sims[1].run(1)
+        st_b = ctx.closed_loop_stats(reset=True)
+        a, b = sims[0].snapshot(), sims[1].snapshot()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (B, k)
+        assert st_a == st_b and st_a['agent_steps'] == 21 * B * 8, (st_a, st_b)
+        assert (a['status'] == 0).all()
+
+
 def test_arc_length_table_changes_nothing(ctx):
     """mpcx_interaction_params.path_cum (round 3): the conflict search takes its resampling buckets from the caller's arc-length table where
     that is safe.  Same integer outputs, bit for bit, as deriving the step lengths from the points -- on a batch in the middle of its run
