@@ -120,16 +120,19 @@ struct RollArgs {
 // divide) per instance), results staged in LDS and written as ONE contiguous run: the 64 instances' xbar rows are adjacent in memory
 // (64 x 4 x (T+1) doubles).  Until round 3 every lane stored its doubles straight to memory, 8 bytes at a 4 (T+1) x 8-byte lane stride,
 // each its own write transaction: 165 MB of write traffic for 45 MB of output.
-constexpr int ROLL_W_MAX = MPCX_T_MAX + 1;
+// (round 4: the staging buffer is dynamic LDS sized for the horizon in use -- 43.5 KB at T = 20 instead of 68 KB for T = 32: this kernel runs
+// beside the conflict search on the side stream, and its two workgroups per CU left that kernel's 6.5-KB workgroups 24 KB of a CU's LDS)
 __global__ __launch_bounds__(64) void rollout_kernel(RollArgs a) {
-    __shared__ double s_x[64][4 * ROLL_W_MAX + 1];      // +1: rows of 4 W doubles would sit 8 lanes to a bank group
+    extern __shared__ double s_roll[];                   // [64][4 W + 1]; +1: rows of 4 W doubles would sit 8 lanes to a bank group
     const int T = a.p.T, W = T + 1;
+    const int RS = 4 * W + 1;
+    auto s_x = [&](int lane) -> double * { return s_roll + (size_t)lane * RS; };
     const int b0 = (int)blockIdx.x * 64;
     const int n = a.B - b0 < 64 ? a.B - b0 : 64;
     if (threadIdx.x < (unsigned)n) {
         const int b = b0 + (int)threadIdx.x;
         double x = a.state[4 * b], y = a.state[4 * b + 1], v = a.state[4 * b + 2], th = a.state[4 * b + 3];
-        double *xb = s_x[threadIdx.x];
+        double *xb = s_x(threadIdx.x);
         xb[0] = x; xb[W] = y; xb[2 * W] = v; xb[3 * W] = th;
         const double *oa = a.u_warm ? a.u_warm + (size_t)b * 2 * T : nullptr;
         for (int t = 1; t <= T; t++) {
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RollArgs a) {
     }
     __syncthreads();
     double *out = a.xbar + (size_t)b0 * 4 * W;
-    for (int i = threadIdx.x; i < n * 4 * W; i += blockDim.x) out[i] = s_x[i / (4 * W)][i % (4 * W)];
+    for (int i = threadIdx.x; i < n * 4 * W; i += blockDim.x) out[i] = s_x(i / (4 * W))[i % (4 * W)];
 }
 
 // The two halves of mpc.py:211-239's preparation are independent -- the rollout is a chain of T dependent sincos / tan evaluations per
@@ -257,7 +260,7 @@ int32_t mpcx_rollout_fork(mpcx_ctx *ctx, int32_t B, const double *state, const d
     mpcx::RollArgs ro{ctx->mpc, B, state, u_warm, xbar};
     if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0) != hipSuccess)
         return mpcx_fail(ctx, MPCX_E_LAUNCH, "mpc_prepare_batch: cannot fork the side stream");
-    hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->side, ro);
+    hipLaunchKernelGGL(mpcx::rollout_kernel, dim3((B + 63) / 64), dim3(64), 64 * (4 * (size_t)(ctx->mpc.T + 1) + 1) * sizeof(double), ctx->side, ro);
     // the join event right behind the rollout: by the time the context's stream waits for it (in front of the solve) the marker has long
     // been processed -- recorded there, the wait paid for the side queue's marker AND its own barrier
     if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess)
