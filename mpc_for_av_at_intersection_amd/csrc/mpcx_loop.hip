@@ -6,6 +6,7 @@
 // by one from the host.
 #include "mpcx_common.h"
 #include <cstring>
+#include <cstdlib>
 
 namespace mpcx {
 
@@ -34,9 +35,12 @@ static int32_t enqueue_step(mpcx_ctx *ctx, const mpcx_interaction_params *ip, co
     int32_t rc, pool_rows = P;
     // the warm-start rollout of this step needs only the states and the previous solution: it runs on the side stream BESIDE the pool pack,
     // the prediction and the conflict search (a chain of T dependent sincos / tan per agent, 35-45 us) and is joined by the window selection
-    rc = mpcx_rollout_fork(ctx, P, c->state, c->u_sol, c->xbar);
-    if (rc != MPCX_OK) return rc;
-    ctx->rollout_forked = true;
+    static const bool late_fork = getenv("MPCX_DEV_LATE_ROLLOUT") != nullptr;      // dev aid: the rollout beside the window selection instead of beside the conflict search
+    if (!late_fork) {
+        rc = mpcx_rollout_fork(ctx, P, c->state, c->u_sol, c->xbar);
+        if (rc != MPCX_OK) return rc;
+        ctx->rollout_forked = true;
+    }
     if (c->exchange == MPCX_SHARD_AGENTS) {
         // agent-sharded layout: this rank's rows travel to every rank, every rank assembles the whole pool (one RCCL all-gather)
         mpcx::PackArgs pa{P, c->state, c->applied, c->obs_local};
