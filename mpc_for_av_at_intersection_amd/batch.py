@@ -78,12 +78,14 @@ class IntersectionBatch:
         pkey = (hash(table.tobytes()), tuple(int(o) for o in offs), float(ip.dt), float(ip.max_speed), tuple(float(v) for v in np.asarray(ip.circle_centers).ravel()),
                 float(ip.radius), int(ip.pred_steps))
         pl = _PLAN_CACHE.get(pkey)
+        if pl is None and len(table) * 64 * 32 > (256 << 20):
+            pl = False                   # 2 KB of table per path point: beyond 256 MB the kernels resample instead (identical outputs)
         if pl is None:                   # (a few tenths of a second per set of routes: numpy over every start point of every route)
             if len(_PLAN_CACHE) > 8:
                 _PLAN_CACHE.clear()
             pl = _PLAN_CACHE[pkey] = path_plan(table, np.column_stack([np.cos(table[:, 2]), np.sin(table[:, 2])]), offs, ip.dt, ip.max_speed,
                                                ip.circle_centers, ip.radius, ip.pred_steps)
-        self.plan = dict(pl, cnt=ctx.i32(pl['cnt']), disc=ctx.f64(pl['disc']), box=ctx.f64(pl['box']), path_disc=ctx.f64(pl['path_disc']))
+        self.plan = dict(pl, cnt=ctx.i32(pl['cnt']), disc=ctx.f64(pl['disc']), box=ctx.f64(pl['box']), path_disc=ctx.f64(pl['path_disc'])) if pl else None
         ip.plan = self.plan
         r = route_of_agent.reshape(-1)
         s = start_index.reshape(-1)
